@@ -1,0 +1,210 @@
+/* =============================================================================
+ * rrt.h -- C ABI of the MI355X (gfx950) tracing core for rustraytracer scenes.
+ *
+ * The reference (rishabh-bector/rustraytracer) has no FFI layer; its operator
+ * API is the Rust traits Entity / RayBehavior / LightSource plus the
+ * constructors that main.rs calls.  The cut point is
+ *     RayTracer::render(self, output, world)        src/tracer.rs:77
+ * Everything above it (scene set-up, file I/O) stays on the host; everything
+ * below it (ray generation, closest hit, shading, sky lookup, quantisation)
+ * is one blocking call into this library.  Because `dyn` traits are open sets
+ * and a GPU needs closed ones, the ABI is a scene-description API over the
+ * closed set the reference ships: entity kinds {sphere, triangle mesh + rope
+ * kd-tree}, behaviour kinds {lambert, reflection, phong, cubemap}, light kinds
+ * {directional}.  Each entry point cites the reference interface it replaces.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types.  All functions
+ * returning int return RRT_OK (0) or a negative RRT_E_* code; the message is
+ * available from rrt_last_error() (thread-local).  Nothing throws or aborts
+ * across the boundary (the reference panics: cubemap.rs:19-44, model.rs:26-27).
+ * The library copies every input at the call (the caller may free at once);
+ * the caller owns all output buffers.  One scene handle is not re-entrant;
+ * distinct handles may be used from distinct threads.
+ * ========================================================================== */
+#ifndef RRT_H
+#define RRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRT_OK 0
+#define RRT_E_INVALID (-1)   /* bad argument / handle / id                      */
+#define RRT_E_HIP (-2)       /* a HIP runtime call failed                       */
+#define RRT_E_STATE (-3)     /* scene incomplete (no sky set, no device, ...)   */
+#define RRT_E_NOMEM (-4)     /* work buffers do not fit the configured budget   */
+
+typedef struct rrt_scene rrt_scene;
+
+/* Camera of RayTracer::new_default_renderer + the lens set-up at the top of
+ * render (src/tracer.rs:38-51, 84-110): eye, lens plane at eye.z + lens_z,
+ * lens of lens_w x lens_h world units centred on the eye's x/y.  The
+ * reference's values are {0,0,0}, 75, 160, 90 (rrt_default_camera). */
+typedef struct rrt_camera {
+    double eye[3];
+    double lens_z;
+    double lens_w;
+    double lens_h;
+} rrt_camera;
+
+/* RenderSettings (src/tracer.rs:16-18) plus the build's extensions.
+ * Reference behaviour = {W, H, spp 1, max_bounce 2, seed any, prune 0}.
+ *   spp          samples per pixel.  Sample 0 is always the reference's ray
+ *                through the pixel's top-left corner (tracer.rs:128-131);
+ *                samples s>=1 add a jitter in [0,1)^2 pixel units drawn from
+ *                Philox4x32-10(counter = {pixel, s, 0, 0}, key = seed).
+ *                The pixel is quantised from (sum over s in order) / spp.
+ *   max_bounce   ReflectionBehavior's literal `2` (reflection.rs:26): a
+ *                reflection ray is spawned while ray.bounce <= max_bounce.
+ *   prune_zero_mix  1 = do not trace reflection rays whose mix is exactly 0.0
+ *                (value-identical; changes the ray count).
+ *   tile_rank/tile_world  image-tile sharding: 32x8-pixel tiles, tile t (row
+ *                major over the tile grid) belongs to rank t % tile_world.
+ *                tile_world = 1 renders the whole frame.
+ *   batch_spp    samples per pixel per wavefront batch; 0 = choose from the
+ *                work-memory budget (rrt_set_work_budget). */
+typedef struct rrt_settings {
+    uint32_t width;
+    uint32_t height;
+    uint32_t spp;
+    uint32_t max_bounce;
+    uint64_t seed;
+    uint32_t prune_zero_mix;
+    uint32_t tile_rank;
+    uint32_t tile_world;
+    uint32_t batch_spp;
+} rrt_settings;
+
+/* Filled by rrt_get_stats after a render. */
+typedef struct rrt_stats {
+    uint64_t rays_traced;      /* closest-hit queries (= cast() invocations, tracer.rs:177) executed */
+    uint64_t primary_rays;     /* of which primary                                                    */
+    uint64_t paths;            /* pixel samples                                                       */
+    uint64_t traversal_overflow; /* rays that exceeded the leaf-visit safety bound (expected 0)       */
+    double gpu_ms;             /* hipEvent span of the last render's kernels                          */
+    double trace_kernel_ms;    /* summed duration of the trace+shade kernels only                     */
+    uint32_t trace_kernel_launches;
+    uint32_t n_batches;
+} rrt_stats;
+
+#define RRT_TILE_W 32
+#define RRT_TILE_H 8
+
+const char* rrt_last_error(void);
+const char* rrt_version(void);
+
+/* Selects the HIP device used by scenes created afterwards on this thread
+ * (one process per GPU: pass LOCAL_RANK). */
+int rrt_set_device(int device);
+
+/* 1 if the device reports HIP image/texture support, 0 if not, <0 on error. */
+int rrt_device_image_support(void);
+
+void rrt_default_camera(rrt_camera* cam);                       /* tracer.rs:38-51 */
+void rrt_default_settings(rrt_settings* st, uint32_t w, uint32_t h);
+
+/* World (src/common.rs:10-15) ------------------------------------------------ */
+rrt_scene* rrt_scene_create(void);                              /* RayTracer::new_empty_world's empty World */
+void rrt_scene_destroy(rrt_scene* s);
+
+/* Material::new_lambert_material(color, albedo, lambert, reflective, phong,
+ * alpha) (src/material.rs:20-33): shaders [Lambert, Reflection, Phong].
+ * Returns the material id (>= 0) or a negative error. */
+int rrt_add_material(rrt_scene* s, const double color[3], double albedo, double lambert_mix,
+                     double reflective_mix, double phong_mix, int32_t alpha);
+
+/* Sphere::new(position, radius, material) + world.entities.push
+ * (src/geometry/sphere.rs:17-24, src/main.rs:62).  Returns the entity id =
+ * insertion order, as the reference's entity list. */
+int rrt_add_sphere(rrt_scene* s, const double center[3], double radius, int material);
+
+/* The Triangle list Model::new produces (src/geometry/model.rs:31-45) + the
+ * KDTree::new it builds (src/geometry/kdtree.rs:46-51) + world.entities.push.
+ * verts: 9 doubles per triangle (v0,v1,v2 after the model transform);
+ * normals: 3 doubles per triangle (the flat averaged normal).  The kd-tree is
+ * built inside with the reference's algorithm (kdtree.rs:53-190) including
+ * the tie order of its sort_unstable_by.  Returns the entity id. */
+int rrt_add_mesh(rrt_scene* s, const double* verts, const double* normals, int64_t n_triangles, int material);
+
+/* Material::new_sky_material / CubemapBehavior::new (src/material.rs:35-42,
+ * src/behavior/cubemap.rs:16-52) after the PNGs are decoded to RGB8 by the
+ * host.  face index = position in the reference's maps[] array
+ * [left,right,down,up,front,back] (cubemap.rs:47-48). rgb8: h rows of w texels. */
+int rrt_set_sky_face(rrt_scene* s, int face, const uint8_t* rgb8, uint32_t w, uint32_t h);
+
+/* DirectionalLight::new(direction, color, intensity) (src/lighting.rs:25-32;
+ * direction is normalised inside, as there).  The reference world holds
+ * exactly one (tracer.rs:55-65); a second call replaces it. */
+int rrt_set_directional_light(rrt_scene* s, const double direction[3], const double color[3], double intensity);
+
+int rrt_set_ambient(rrt_scene* s, double ambient);             /* World.ambient, tracer.rs:73 */
+
+/* Upper bound in bytes for per-render wavefront work buffers (queues, path
+ * records, sample buffer).  Default 4 GiB. */
+int rrt_set_work_budget(rrt_scene* s, uint64_t bytes);
+
+/* Uploads the scene to the device (idempotent; render calls it if needed). */
+int rrt_scene_commit(rrt_scene* s);
+
+/* RayTracer::render (src/tracer.rs:77-175) minus the PNG save: blocking.
+ * out_rgb8  [H][W][3] bytes, vec_rgb quantisation (common.rs:75-81)   (may be NULL)
+ * out_ids   [H][W][2] int32 {entity id, triangle id} of the sample-0 primary
+ *           hit; entity -1 = sky, triangle -1 = not a mesh            (may be NULL)
+ * out_t     [H][W] f64 hit parameter t of that hit (0 for sky)        (may be NULL)
+ * out_color [H][W][3] f64 un-quantised mean colour                    (may be NULL)
+ * Requires tile_world == 1. */
+int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint8_t* out_rgb8, int32_t* out_ids,
+               double* out_t, double* out_color);
+
+/* Same with DEVICE output pointers, asynchronous on `stream` (a hipStream_t,
+ * NULL = default stream).  With tile_world > 1 d_rgb8 is this rank's compact
+ * tile buffer [rrt_tile_slots()][RRT_TILE_H][RRT_TILE_W][3] (slot j = tile
+ * j*tile_world + tile_rank) and the AOV pointers must be NULL. */
+int rrt_render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids,
+                      void* d_t, void* d_color, void* stream);
+
+/* Tiles each rank owns (padded to equal size so the gather is regular). */
+int64_t rrt_tile_slots(uint32_t width, uint32_t height, uint32_t tile_world);
+
+/* Root-side de-interleave after the RCCL gather: d_gathered is
+ * [tile_world][slots][RRT_TILE_H][RRT_TILE_W][3]; writes row-major d_rgb8. */
+int rrt_assemble_tiles(const void* d_gathered, uint32_t width, uint32_t height, uint32_t tile_world, void* d_rgb8,
+                       void* stream);
+
+/* The closest-hit loop of RayTracer::cast over world.entities
+ * (src/tracer.rs:178-190 calling Entity::collide, common.rs:42) for caller
+ * supplied rays (6 doubles each: origin, direction).  Host pointers; outputs
+ * may be NULL.  ent -1 = miss. */
+int rrt_trace_rays(rrt_scene* s, const double* rays, int64_t n, int32_t* ent, int32_t* tri, double* t, double* pos,
+                   double* normal);
+
+/* RayTracer::cast (src/tracer.rs:177-211) for caller supplied bounce-0 rays:
+ * full shading incl. reflection chain; color: 3 doubles per ray. */
+int rrt_cast_rays(rrt_scene* s, const double* rays, int64_t n, uint32_t max_bounce, uint32_t prune_zero_mix,
+                  double* color);
+
+int rrt_get_stats(const rrt_scene* s, rrt_stats* out);
+
+/* Flattened kd-tree of a mesh entity in pre-order, for inspection and tests.
+ * boxes 6/node, split 1/node, axis 1/node (-1 = leaf), child 2/node (interior:
+ * left,right; leaf: first,count into leaf_refs), ropes 6/node (-1 = none;
+ * index i: 0..2 = -x,-y,-z faces, 3..5 = +x,+y,+z; kdtree.rs:139-190). */
+int rrt_mesh_tree_sizes(const rrt_scene* s, int entity, int32_t* n_nodes, int32_t* n_leaf_refs);
+int rrt_mesh_tree_export(const rrt_scene* s, int entity, double* boxes, double* split, int32_t* axis, int32_t* child,
+                         int32_t* ropes, int32_t* leaf_refs);
+
+/* Device arithmetic self-test used by the parity tests: out[i] = a[i] op b[i]
+ * computed on the GPU in f64 (op 0 = div, 1 = sqrt(a), 2 = a*b+c unfused with
+ * c = b, 3 = powi(a, (int)b)).  Host pointers. */
+int rrt_selftest_math(int op, const double* a, const double* b, int64_t n, double* out);
+
+/* Extension RNG, exposed for known-answer tests (host-side evaluation of the
+ * same function the kernels use). */
+void rrt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRT_H */

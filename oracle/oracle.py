@@ -53,6 +53,7 @@ def lib():
             build()
         L = C.CDLL(so)
         L.orc_scene_create.restype = C.c_void_p
+        L.orc_set_sort_mode.argtypes = [C.c_int]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_add_material.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
         L.orc_add_sphere.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_int]
@@ -64,7 +65,7 @@ def lib():
         L.orc_mesh_tree_export.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
         L.orc_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 6
         L.orc_cast_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint32, C.c_uint32, C.c_void_p]
-        L.orc_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Settings), C.c_int64, C.c_int64] + [C.c_void_p] * 5
+        L.orc_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(Settings), C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 5
         L.orc_render.restype = C.c_int
         L.orc_aabb_collide.argtypes = [C.c_void_p] * 4
         L.orc_triangle_collide.argtypes = [C.c_void_p] * 4 + [C.POINTER(C.c_double)]
@@ -232,7 +233,7 @@ class OracleScene:
         return col
 
     def render(self, width, height, spp=1, max_bounce=2, seed=0, prune_zero_mix=0, n_threads=8,
-               camera=None, p0=0, p1=-1, want=("rgb", "ids", "t", "color")):
+               camera=None, y0=0, y1=-1, row_stride=1, want=("rgb", "ids", "t", "color")):
         cam = camera or default_camera()
         st = Settings(width, height, spp, max_bounce, seed, prune_zero_mix, n_threads)
         npx = width * height
@@ -241,7 +242,7 @@ class OracleScene:
         out["ids"] = np.full((height, width, 2), -2, np.int32) if "ids" in want else None
         out["t"] = np.zeros((height, width)) if "t" in want else None
         out["color"] = np.zeros((height, width, 3)) if "color" in want else None
-        rc = self.L.orc_render(self.h, C.byref(cam), C.byref(st), p0, p1, _ptr(out["rgb"]), _ptr(out["ids"]),
+        rc = self.L.orc_render(self.h, C.byref(cam), C.byref(st), y0, y1, row_stride, _ptr(out["rgb"]), _ptr(out["ids"]),
                                _ptr(out["t"]), _ptr(out["color"]), _ptr(out["counters"]))
         assert rc == 0 and npx > 0
         return out

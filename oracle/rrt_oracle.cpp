@@ -689,48 +689,52 @@ void orc_cast_rays(void* h, const double* rays, int64_t n, uint32_t max_bounce, 
     }
 }
 
-// ---- render (tracer.rs:77-175, minus PNG save).  Pixel range [p0,p1) lets
-// the CPU-baseline leg time a bounded sample.  All outputs are full-frame
-// row-major and may be null.  counters: 7 x u64.
-int orc_render(void* h, const Camera* cam, const Settings* stp, int64_t p0, int64_t p1,
+// ---- render (tracer.rs:77-175, minus PNG save).  Rows y0 <= y < y1 with
+// (y - y0) % row_stride == 0 are rendered (the CPU-baseline leg times a bounded
+// strided sample; tests render everything).  Threads take rows from a shared
+// counter (the reference uses 12 static contiguous chunks, tracer.rs:117-158;
+// dynamic rows only change who computes a pixel, never its value).  All
+// outputs are full-frame row-major and may be null.  counters: 7 x u64.
+int orc_render(void* h, const Camera* cam, const Settings* stp, int64_t y0, int64_t y1, int64_t row_stride,
                uint8_t* out_rgb, int32_t* out_ids, double* out_t, double* out_color, uint64_t* counters) {
     Scene* s = (Scene*)h;
     const Settings st = *stp;
-    if (p0 < 0) p0 = 0;
-    const int64_t npx = (int64_t)st.width * st.height;
-    if (p1 < 0 || p1 > npx) p1 = npx;
+    if (y0 < 0) y0 = 0;
+    if (y1 < 0 || y1 > (int64_t)st.height) y1 = st.height;
+    if (row_stride < 1) row_stride = 1;
     const uint32_t nt = st.n_threads ? st.n_threads : 1;
     std::vector<Counters> cs(nt);
     std::vector<std::thread> th;
-    const int64_t total = p1 - p0;
-    // tracer.rs:117-124 : contiguous row-major chunks, one per thread.
-    const int64_t chunk = (total + nt - 1) / nt;
+    std::atomic<int64_t> next_row{y0};
     for (uint32_t ti = 0; ti < nt; ++ti) {
         th.emplace_back([&, ti]() {
             Counters& c = cs[ti];
-            const int64_t b = p0 + ti * chunk, e = std::min<int64_t>(p1, b + chunk);
-            for (int64_t i = b; i < e; ++i) {
-                const uint32_t x = (uint32_t)(i % st.width), y = (uint32_t)(i / st.width);
-                V3 sum{0, 0, 0};
-                for (uint32_t sp = 0; sp < st.spp; ++sp) {
-                    double jx, jy;
-                    sample_jitter(st, (uint32_t)i, sp, &jx, &jy);
-                    const Ray r = primary_ray(*cam, st, x, y, jx, jy);
-                    Primary prim;
-                    const V3 col = cast(*s, st, r, c, sp == 0 ? &prim : nullptr);
-                    if (sp == 0) {
-                        sum = col;
-                        if (out_ids) { out_ids[2 * i] = prim.ent; out_ids[2 * i + 1] = prim.tri; }
-                        if (out_t) out_t[i] = prim.t;
-                    } else sum = add(sum, col);
-                }
-                const double n = (double)st.spp;
-                const V3 mean{sum.x / n, sum.y / n, sum.z / n};
-                if (out_color) { out_color[3 * i] = mean.x; out_color[3 * i + 1] = mean.y; out_color[3 * i + 2] = mean.z; }
-                if (out_rgb) {   // common.rs:75-81
-                    out_rgb[3 * i] = sat_u8(mean.x * 255.0);
-                    out_rgb[3 * i + 1] = sat_u8(mean.y * 255.0);
-                    out_rgb[3 * i + 2] = sat_u8(mean.z * 255.0);
+            for (;;) {
+                const int64_t y = next_row.fetch_add(row_stride);
+                if (y >= y1) break;
+                for (uint32_t x = 0; x < st.width; ++x) {
+                    const int64_t i = y * st.width + x;
+                    V3 sum{0, 0, 0};
+                    for (uint32_t sp = 0; sp < st.spp; ++sp) {
+                        double jx, jy;
+                        sample_jitter(st, (uint32_t)i, sp, &jx, &jy);
+                        const Ray r = primary_ray(*cam, st, x, (uint32_t)y, jx, jy);
+                        Primary prim;
+                        const V3 col = cast(*s, st, r, c, sp == 0 ? &prim : nullptr);
+                        if (sp == 0) {
+                            sum = col;
+                            if (out_ids) { out_ids[2 * i] = prim.ent; out_ids[2 * i + 1] = prim.tri; }
+                            if (out_t) out_t[i] = prim.t;
+                        } else sum = add(sum, col);
+                    }
+                    const double n = (double)st.spp;
+                    const V3 mean{sum.x / n, sum.y / n, sum.z / n};
+                    if (out_color) { out_color[3 * i] = mean.x; out_color[3 * i + 1] = mean.y; out_color[3 * i + 2] = mean.z; }
+                    if (out_rgb) {   // common.rs:75-81
+                        out_rgb[3 * i] = sat_u8(mean.x * 255.0);
+                        out_rgb[3 * i + 1] = sat_u8(mean.y * 255.0);
+                        out_rgb[3 * i + 2] = sat_u8(mean.z * 255.0);
+                    }
                 }
             }
         });

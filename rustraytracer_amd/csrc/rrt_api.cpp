@@ -1,0 +1,637 @@
+// C ABI (include/rrt.h): scene container, flattening into HBM, wavefront
+// frame scheduling.  Host code only; kernels live in rrt_kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "host_io.hpp"
+#include "kd_build.hpp"
+#include "rrt_device.h"
+
+namespace {
+
+thread_local std::string g_err;
+thread_local int g_device = 0;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RRT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));             \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    hipError_t ensure(size_t n) {
+        if (n <= bytes && p) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(&p, n ? n : 1);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    hipError_t upload(const void* src, size_t n) {
+        hipError_t e = ensure(n);
+        if (e != hipSuccess || n == 0) return e;
+        return hipMemcpy(p, src, n, hipMemcpyHostToDevice);
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+struct HostMesh {
+    std::vector<rrt::DTri> tris;
+    std::vector<double> normals;
+    rrt::KdTreeFlat tree;
+    int material = 0;
+    // device copies
+    DevBuf d_nodes, d_refs, d_tris, d_normals;
+};
+
+struct SkyFace {
+    std::vector<uint8_t> rgb;
+    uint32_t w = 0, h = 0;
+    DevBuf d;
+};
+
+struct TimedLaunch {
+    hipEvent_t a = nullptr, b = nullptr;
+    bool primary = false;
+};
+
+}  // namespace
+
+namespace rrt {
+void set_last_error(const std::string& msg) { g_err = msg; }
+}  // namespace rrt
+
+struct rrt_scene {
+    int device = 0;
+    std::vector<rrt::DMaterial> mats;
+    std::vector<rrt::DSphere> spheres;
+    std::vector<std::unique_ptr<HostMesh>> meshes;
+    std::vector<rrt::DEntity> ents;
+    SkyFace sky[6];
+    bool has_light = false;
+    double light_dir[3] = {0, 0, 0}, light_color[3] = {0, 0, 0}, light_intensity = 0.0;
+    double ambient = 0.15;  // tracer.rs:73
+    uint64_t work_budget = 4ull << 30;
+
+    bool dirty = true;
+    DevBuf d_ents, d_spheres, d_meshes, d_mats;
+    rrt::DScene dscene{};
+
+    // work buffers
+    DevBuf w_qo[2], w_qd[2], w_qpath[2], w_qcount, w_recA, w_recP, w_recR, w_samp, w_accum, w_stats;
+    DevBuf w_ids, w_t, w_color, w_rgb;  // staging for the host-output render
+
+    // timing of the last render
+    std::vector<TimedLaunch> timed;
+    size_t timed_used = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool have_frame = false;
+    rrt_stats stats{};
+
+    ~rrt_scene() {
+        for (auto& t : timed) {
+            if (t.a) (void)hipEventDestroy(t.a);
+            if (t.b) (void)hipEventDestroy(t.b);
+        }
+        if (ev_begin) (void)hipEventDestroy(ev_begin);
+        if (ev_end) (void)hipEventDestroy(ev_end);
+    }
+};
+
+namespace {
+
+int commit(rrt_scene* s) {
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->dirty) return RRT_OK;
+    for (int f = 0; f < 6; ++f)
+        if (s->sky[f].w == 0) return fail(RRT_E_STATE, "sky face " + std::to_string(f) + " not set (rrt_set_sky_face)");
+    std::vector<rrt::DMesh> dm(s->meshes.size());
+    for (size_t i = 0; i < s->meshes.size(); ++i) {
+        HostMesh& m = *s->meshes[i];
+        const rrt::KdTreeFlat& T = m.tree;
+        std::vector<rrt::DNode> nodes((size_t)T.n_nodes());
+        for (size_t k = 0; k < nodes.size(); ++k) {
+            rrt::DNode& n = nodes[k];
+            for (int a = 0; a < 3; ++a) {
+                n.mn[a] = T.boxes[6 * k + a];
+                n.mx[a] = T.boxes[6 * k + 3 + a];
+            }
+            n.split = T.split[k];
+            n.axis = T.axis[k];
+            n.c0 = T.child[2 * k];
+            n.c1 = T.child[2 * k + 1];
+            for (int r = 0; r < 6; ++r) n.rope[r] = T.ropes[6 * k + r];
+            n.pad = 0;
+        }
+        HIP_TRY(m.d_nodes.upload(nodes.data(), nodes.size() * sizeof(rrt::DNode)));
+        HIP_TRY(m.d_refs.upload(T.leaf_refs.data(), T.leaf_refs.size() * sizeof(int32_t)));
+        HIP_TRY(m.d_tris.upload(m.tris.data(), m.tris.size() * sizeof(rrt::DTri)));
+        HIP_TRY(m.d_normals.upload(m.normals.data(), m.normals.size() * sizeof(double)));
+        dm[i].nodes = m.d_nodes.as<rrt::DNode>();
+        dm[i].leaf_refs = m.d_refs.as<int32_t>();
+        dm[i].tris = m.d_tris.as<rrt::DTri>();
+        dm[i].normals = m.d_normals.as<double>();
+        dm[i].material = m.material;
+        dm[i].n_nodes = T.n_nodes();
+    }
+    HIP_TRY(s->d_meshes.upload(dm.data(), dm.size() * sizeof(rrt::DMesh)));
+    HIP_TRY(s->d_spheres.upload(s->spheres.data(), s->spheres.size() * sizeof(rrt::DSphere)));
+    HIP_TRY(s->d_mats.upload(s->mats.data(), s->mats.size() * sizeof(rrt::DMaterial)));
+    HIP_TRY(s->d_ents.upload(s->ents.data(), s->ents.size() * sizeof(rrt::DEntity)));
+    rrt::DScene& d = s->dscene;
+    d.ents = s->d_ents.as<rrt::DEntity>();
+    d.spheres = s->d_spheres.as<rrt::DSphere>();
+    d.meshes = s->d_meshes.as<rrt::DMesh>();
+    d.mats = s->d_mats.as<rrt::DMaterial>();
+    d.n_ents = (int32_t)s->ents.size();
+    d.has_light = s->has_light ? 1 : 0;
+    for (int a = 0; a < 3; ++a) {
+        d.light_dir[a] = s->light_dir[a];
+        d.light_color[a] = s->light_color[a];
+    }
+    d.light_intensity = s->light_intensity;
+    d.ambient = s->ambient;
+    for (int f = 0; f < 6; ++f) {
+        HIP_TRY(s->sky[f].d.upload(s->sky[f].rgb.data(), s->sky[f].rgb.size()));
+        d.sky[f] = s->sky[f].d.as<uint8_t>();
+        d.sky_w[f] = s->sky[f].w;
+        d.sky_h[f] = s->sky[f].h;
+    }
+    s->dirty = false;
+    return RRT_OK;
+}
+
+struct FramePlan {
+    rrt::DFrame fr{};
+    uint32_t levels = 0;
+    uint32_t batch_spp = 0;
+    uint32_t n_batches = 0;
+    uint64_t cap = 0;  // paths per batch
+    uint64_t valid_px = 0;
+};
+
+size_t bytes_per_path(uint32_t levels) {
+    return (size_t)levels * 7 * 8   // recA + recP + recR
+           + 3 * 8                  // samp
+           + 2 * (6 * 8 + 4);       // two queues
+}
+
+int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, FramePlan* out) {
+    if (!cam || !st) return fail(RRT_E_INVALID, "null camera/settings");
+    if (st->width == 0 || st->height == 0 || st->spp == 0) return fail(RRT_E_INVALID, "width, height and spp must be > 0");
+    if ((uint64_t)st->width * st->height > 0x7fffffffull) return fail(RRT_E_INVALID, "image too large");
+    if (st->max_bounce + 2 > (uint32_t)rrt::kMaxLevels) return fail(RRT_E_INVALID, "max_bounce too large (<= 16)");
+    if (st->tile_world == 0 || st->tile_rank >= st->tile_world) return fail(RRT_E_INVALID, "bad tile_rank/tile_world");
+    rrt::DFrame& fr = out->fr;
+    fr.cam = *cam;
+    fr.width = st->width;
+    fr.height = st->height;
+    fr.spp = st->spp;
+    fr.max_bounce = st->max_bounce;
+    fr.seed_lo = (uint32_t)st->seed;
+    fr.seed_hi = (uint32_t)(st->seed >> 32);
+    fr.prune = st->prune_zero_mix ? 1u : 0u;
+    fr.tile_rank = st->tile_rank;
+    fr.tile_world = st->tile_world;
+    fr.tiles_x = (st->width + RRT_TILE_W - 1) / RRT_TILE_W;
+    fr.tiles_y = (st->height + RRT_TILE_H - 1) / RRT_TILE_H;
+    const uint64_t n_tiles = (uint64_t)fr.tiles_x * fr.tiles_y;
+    fr.n_slots = (uint32_t)((n_tiles + st->tile_world - 1) / st->tile_world);
+    fr.npx_local = fr.n_slots * 256u;
+    out->levels = st->max_bounce + 2;
+    const size_t bpp = bytes_per_path(out->levels);
+    uint64_t max_spp = s->work_budget / ((uint64_t)bpp * fr.npx_local);
+    if (st->batch_spp) max_spp = st->batch_spp;
+    if (max_spp == 0) return fail(RRT_E_NOMEM, "work budget too small for one sample per pixel (rrt_set_work_budget)");
+    // keep path ids in 32 bits
+    max_spp = std::min<uint64_t>(max_spp, 0xffffffffull / fr.npx_local);
+    if (max_spp == 0) return fail(RRT_E_NOMEM, "frame too large");
+    out->n_batches = (uint32_t)((st->spp + max_spp - 1) / max_spp);
+    out->batch_spp = (st->spp + out->n_batches - 1) / out->n_batches;
+    out->cap = (uint64_t)out->batch_spp * fr.npx_local;
+    // pixels this rank really owns
+    uint64_t valid = 0;
+    for (uint32_t slot = 0; slot < fr.n_slots; ++slot) {
+        const uint64_t tile = (uint64_t)slot * st->tile_world + st->tile_rank;
+        if (tile >= n_tiles) continue;
+        const uint32_t tx = (uint32_t)(tile % fr.tiles_x), ty = (uint32_t)(tile / fr.tiles_x);
+        const uint32_t w = std::min<uint32_t>(RRT_TILE_W, st->width - tx * RRT_TILE_W);
+        const uint32_t h = std::min<uint32_t>(RRT_TILE_H, st->height - ty * RRT_TILE_H);
+        valid += (uint64_t)w * h;
+    }
+    out->valid_px = valid;
+    return RRT_OK;
+}
+
+int ensure_work(rrt_scene* s, const FramePlan& pl, rrt::DWork* wk) {
+    const uint64_t P = pl.cap;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(s->w_qo[i].ensure(P * 3 * 8));
+        HIP_TRY(s->w_qd[i].ensure(P * 3 * 8));
+        HIP_TRY(s->w_qpath[i].ensure(P * 4));
+        wk->q[i].o = s->w_qo[i].as<double>();
+        wk->q[i].d = s->w_qd[i].as<double>();
+        wk->q[i].path = s->w_qpath[i].as<uint32_t>();
+    }
+    HIP_TRY(s->w_qcount.ensure((rrt::kMaxLevels + 1) * 4));
+    HIP_TRY(s->w_recA.ensure(P * 3 * 8 * pl.levels));
+    HIP_TRY(s->w_recP.ensure(P * 3 * 8 * pl.levels));
+    HIP_TRY(s->w_recR.ensure(P * 8 * pl.levels));
+    HIP_TRY(s->w_samp.ensure(P * 3 * 8));
+    HIP_TRY(s->w_accum.ensure((size_t)pl.fr.npx_local * 3 * 8));
+    HIP_TRY(s->w_stats.ensure(4 * 8));
+    wk->q_count = s->w_qcount.as<uint32_t>();
+    wk->recA = s->w_recA.as<double>();
+    wk->recP = s->w_recP.as<double>();
+    wk->recR = s->w_recR.as<double>();
+    wk->samp = s->w_samp.as<double>();
+    wk->accum = s->w_accum.as<double>();
+    wk->stats = s->w_stats.as<unsigned long long>();
+    wk->cap = P;
+    return RRT_OK;
+}
+
+int timed_slot(rrt_scene* s, TimedLaunch** out) {
+    if (s->timed_used == s->timed.size()) {
+        TimedLaunch t;
+        HIP_TRY(hipEventCreate(&t.a));
+        HIP_TRY(hipEventCreate(&t.b));
+        s->timed.push_back(t);
+    }
+    *out = &s->timed[s->timed_used++];
+    return RRT_OK;
+}
+
+int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids, void* d_t,
+                  void* d_color, void* stream_v) {
+    if (!s) return fail(RRT_E_INVALID, "null scene");
+    FramePlan pl;
+    int rc = plan_frame(s, cam, st, &pl);
+    if (rc) return rc;
+    if (st->tile_world > 1 && (d_ids || d_t || d_color))
+        return fail(RRT_E_INVALID, "AOV / f64 colour outputs need tile_world == 1");
+    rc = commit(s);
+    if (rc) return rc;
+    rrt::DWork wk{};
+    rc = ensure_work(s, pl, &wk);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_v;
+    if (!s->ev_begin) {
+        HIP_TRY(hipEventCreate(&s->ev_begin));
+        HIP_TRY(hipEventCreate(&s->ev_end));
+    }
+    s->timed_used = 0;
+    HIP_TRY(hipEventRecord(s->ev_begin, stream));
+    HIP_TRY(hipMemsetAsync(wk.stats, 0, 4 * 8, stream));
+    rrt::DFrame fr = pl.fr;
+    for (uint32_t b = 0; b < pl.n_batches; ++b) {
+        fr.s0 = b * pl.batch_spp;
+        fr.ns = std::min(pl.batch_spp, st->spp - fr.s0);
+        HIP_TRY(hipMemsetAsync(wk.q_count, 0, (rrt::kMaxLevels + 1) * 4, stream));
+        TimedLaunch* tl;
+        rc = timed_slot(s, &tl);
+        if (rc) return rc;
+        tl->primary = true;
+        HIP_TRY(hipEventRecord(tl->a, stream));
+        rrt::launch_primary(s->dscene, wk, fr, (int32_t*)d_ids, (double*)d_t, stream);
+        HIP_TRY(hipEventRecord(tl->b, stream));
+        for (uint32_t bounce = 1; bounce <= st->max_bounce + 1; ++bounce) {
+            rc = timed_slot(s, &tl);
+            if (rc) return rc;
+            tl->primary = false;
+            HIP_TRY(hipEventRecord(tl->a, stream));
+            rrt::launch_bounce(s->dscene, wk, fr, bounce, stream);
+            HIP_TRY(hipEventRecord(tl->b, stream));
+        }
+        rrt::launch_accumulate(wk, fr, stream);
+    }
+    rrt::launch_resolve(wk, fr, (uint8_t*)d_rgb8, (double*)d_color, stream);
+    HIP_TRY(hipEventRecord(s->ev_end, stream));
+    HIP_TRY(hipGetLastError());
+    s->have_frame = true;
+    s->stats = rrt_stats{};
+    s->stats.paths = pl.valid_px * st->spp;
+    s->stats.primary_rays = s->stats.paths;
+    s->stats.n_batches = pl.n_batches;
+    return RRT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rrt_last_error(void) { return g_err.c_str(); }
+const char* rrt_version(void) { return "rustraytracer_amd 0.1 (gfx950)"; }
+
+int rrt_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    g_device = device;
+    return RRT_OK;
+}
+
+int rrt_device_image_support(void) {
+    int v = 0;
+    HIP_TRY(hipDeviceGetAttribute(&v, hipDeviceAttributeImageSupport, g_device));
+    return v;
+}
+
+void rrt_default_camera(rrt_camera* cam) {
+    cam->eye[0] = cam->eye[1] = cam->eye[2] = 0.0;
+    cam->lens_z = 75.0;
+    cam->lens_w = 160.0;
+    cam->lens_h = 90.0;
+}
+
+void rrt_default_settings(rrt_settings* st, uint32_t w, uint32_t h) {
+    std::memset(st, 0, sizeof(*st));
+    st->width = w;
+    st->height = h;
+    st->spp = 1;
+    st->max_bounce = 2;
+    st->tile_world = 1;
+}
+
+rrt_scene* rrt_scene_create(void) {
+    rrt_scene* s = new (std::nothrow) rrt_scene();
+    if (s) s->device = g_device;
+    return s;
+}
+
+void rrt_scene_destroy(rrt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    delete s;
+}
+
+int rrt_add_material(rrt_scene* s, const double color[3], double albedo, double lambert_mix, double reflective_mix,
+                     double phong_mix, int32_t alpha) {
+    if (!s || !color) return fail(RRT_E_INVALID, "null argument");
+    rrt::DMaterial m{};
+    for (int a = 0; a < 3; ++a) m.color[a] = color[a];
+    m.albedo = albedo;
+    m.mixL = lambert_mix;
+    m.mixR = reflective_mix;
+    m.mixP = phong_mix;
+    m.alpha = alpha;
+    s->mats.push_back(m);
+    s->dirty = true;
+    return (int)s->mats.size() - 1;
+}
+
+int rrt_add_sphere(rrt_scene* s, const double center[3], double radius, int material) {
+    if (!s || !center) return fail(RRT_E_INVALID, "null argument");
+    if (material < 0 || material >= (int)s->mats.size()) return fail(RRT_E_INVALID, "unknown material id");
+    rrt::DSphere sp{};
+    for (int a = 0; a < 3; ++a) sp.c[a] = center[a];
+    sp.r2 = radius * radius;  // radius.powi(2), sphere.rs:21
+    sp.material = material;
+    s->spheres.push_back(sp);
+    s->ents.push_back(rrt::DEntity{0, (int32_t)s->spheres.size() - 1});
+    s->dirty = true;
+    return (int)s->ents.size() - 1;
+}
+
+int rrt_add_mesh(rrt_scene* s, const double* verts, const double* normals, int64_t n, int material) {
+    if (!s || !verts || !normals) return fail(RRT_E_INVALID, "null argument");
+    if (n <= 0 || n > 0x3fffffff) return fail(RRT_E_INVALID, "triangle count out of range");
+    if (material < 0 || material >= (int)s->mats.size()) return fail(RRT_E_INVALID, "unknown material id");
+    auto m = std::make_unique<HostMesh>();
+    m->material = material;
+    m->tris.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const double* v = verts + 9 * i;
+        rrt::DTri& t = m->tris[(size_t)i];
+        for (int a = 0; a < 3; ++a) {
+            t.v0[a] = v[a];
+            t.e1[a] = v[3 + a] - v[a];  // triangle.rs:30
+            t.e2[a] = v[6 + a] - v[a];  // triangle.rs:31
+        }
+    }
+    m->normals.assign(normals, normals + 3 * n);
+    m->tree = rrt::build_kd_tree(verts, n);
+    s->meshes.push_back(std::move(m));
+    s->ents.push_back(rrt::DEntity{1, (int32_t)s->meshes.size() - 1});
+    s->dirty = true;
+    return (int)s->ents.size() - 1;
+}
+
+int rrt_set_sky_face(rrt_scene* s, int face, const uint8_t* rgb8, uint32_t w, uint32_t h) {
+    if (!s || !rgb8) return fail(RRT_E_INVALID, "null argument");
+    if (face < 0 || face > 5 || w == 0 || h == 0) return fail(RRT_E_INVALID, "bad face index or size");
+    s->sky[face].rgb.assign(rgb8, rgb8 + (size_t)w * h * 3);
+    s->sky[face].w = w;
+    s->sky[face].h = h;
+    s->dirty = true;
+    return RRT_OK;
+}
+
+int rrt_set_directional_light(rrt_scene* s, const double direction[3], const double color[3], double intensity) {
+    if (!s || !direction || !color) return fail(RRT_E_INVALID, "null argument");
+    // InnerSpace::normalize, lighting.rs:26 (v * (1/|v|))
+    const double m2 = direction[0] * direction[0] + direction[1] * direction[1] + direction[2] * direction[2];
+    const double inv = 1.0 / std::sqrt(m2);
+    for (int a = 0; a < 3; ++a) {
+        s->light_dir[a] = direction[a] * inv;
+        s->light_color[a] = color[a];
+    }
+    s->light_intensity = intensity;
+    s->has_light = true;
+    s->dirty = true;
+    return RRT_OK;
+}
+
+int rrt_set_ambient(rrt_scene* s, double ambient) {
+    if (!s) return fail(RRT_E_INVALID, "null scene");
+    s->ambient = ambient;
+    s->dirty = true;
+    return RRT_OK;
+}
+
+int rrt_set_work_budget(rrt_scene* s, uint64_t bytes) {
+    if (!s) return fail(RRT_E_INVALID, "null scene");
+    s->work_budget = bytes;
+    return RRT_OK;
+}
+
+int rrt_scene_commit(rrt_scene* s) {
+    if (!s) return fail(RRT_E_INVALID, "null scene");
+    return commit(s);
+}
+
+int64_t rrt_tile_slots(uint32_t width, uint32_t height, uint32_t tile_world) {
+    if (tile_world == 0) return 0;
+    const uint64_t tx = (width + RRT_TILE_W - 1) / RRT_TILE_W, ty = (height + RRT_TILE_H - 1) / RRT_TILE_H;
+    return (int64_t)((tx * ty + tile_world - 1) / tile_world);
+}
+
+int rrt_render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids, void* d_t,
+                      void* d_color, void* stream) {
+    return render_device(s, cam, st, d_rgb8, d_ids, d_t, d_color, stream);
+}
+
+int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint8_t* out_rgb8, int32_t* out_ids,
+               double* out_t, double* out_color) {
+    if (!s || !st) return fail(RRT_E_INVALID, "null argument");
+    if (st->tile_world != 1) return fail(RRT_E_INVALID, "rrt_render needs tile_world == 1");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t npx = (size_t)st->width * st->height;
+    if (out_rgb8) HIP_TRY(s->w_rgb.ensure(npx * 3));
+    if (out_ids) HIP_TRY(s->w_ids.ensure(npx * 8));
+    if (out_t) HIP_TRY(s->w_t.ensure(npx * 8));
+    if (out_color) HIP_TRY(s->w_color.ensure(npx * 24));
+    int rc = render_device(s, cam, st, out_rgb8 ? s->w_rgb.p : nullptr, out_ids ? s->w_ids.p : nullptr,
+                           out_t ? s->w_t.p : nullptr, out_color ? s->w_color.p : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (out_rgb8) HIP_TRY(hipMemcpy(out_rgb8, s->w_rgb.p, npx * 3, hipMemcpyDeviceToHost));
+    if (out_ids) HIP_TRY(hipMemcpy(out_ids, s->w_ids.p, npx * 8, hipMemcpyDeviceToHost));
+    if (out_t) HIP_TRY(hipMemcpy(out_t, s->w_t.p, npx * 8, hipMemcpyDeviceToHost));
+    if (out_color) HIP_TRY(hipMemcpy(out_color, s->w_color.p, npx * 24, hipMemcpyDeviceToHost));
+    return RRT_OK;
+}
+
+int rrt_assemble_tiles(const void* d_gathered, uint32_t width, uint32_t height, uint32_t tile_world, void* d_rgb8,
+                       void* stream) {
+    if (!d_gathered || !d_rgb8 || tile_world == 0 || width == 0 || height == 0)
+        return fail(RRT_E_INVALID, "bad argument");
+    rrt::launch_assemble((const uint8_t*)d_gathered, width, height, tile_world, (uint8_t*)d_rgb8, stream);
+    HIP_TRY(hipGetLastError());
+    return RRT_OK;
+}
+
+static int ray_query(rrt_scene* s, const double* rays, int64_t n, bool cast, uint32_t max_bounce, uint32_t prune,
+                     int32_t* ent, int32_t* tri, double* t, double* pos, double* nrm, double* color) {
+    if (!s || !rays || n < 0) return fail(RRT_E_INVALID, "bad argument");
+    if (cast && max_bounce + 2 > (uint32_t)rrt::kMaxLevels) return fail(RRT_E_INVALID, "max_bounce too large (<= 16)");
+    if (n == 0) return RRT_OK;
+    int rc = commit(s);
+    if (rc) return rc;
+    DevBuf d_rays, d_ent, d_tri, d_t, d_pos, d_nrm, d_col, d_stats;
+    HIP_TRY(d_rays.upload(rays, (size_t)n * 48));
+    HIP_TRY(d_stats.ensure(32));
+    HIP_TRY(hipMemset(d_stats.p, 0, 32));
+    if (cast) {
+        HIP_TRY(d_col.ensure((size_t)n * 24));
+        rrt::launch_cast_rays(s->dscene, d_rays.as<double>(), n, max_bounce, prune, d_col.as<double>(),
+                              d_stats.as<unsigned long long>(), nullptr);
+    } else {
+        if (ent) HIP_TRY(d_ent.ensure((size_t)n * 4));
+        if (tri) HIP_TRY(d_tri.ensure((size_t)n * 4));
+        if (t) HIP_TRY(d_t.ensure((size_t)n * 8));
+        if (pos) HIP_TRY(d_pos.ensure((size_t)n * 24));
+        if (nrm) HIP_TRY(d_nrm.ensure((size_t)n * 24));
+        rrt::launch_trace_rays(s->dscene, d_rays.as<double>(), n, ent ? d_ent.as<int32_t>() : nullptr,
+                               tri ? d_tri.as<int32_t>() : nullptr, t ? d_t.as<double>() : nullptr,
+                               pos ? d_pos.as<double>() : nullptr, nrm ? d_nrm.as<double>() : nullptr,
+                               d_stats.as<unsigned long long>(), nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (cast) HIP_TRY(hipMemcpy(color, d_col.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (ent) HIP_TRY(hipMemcpy(ent, d_ent.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (tri) HIP_TRY(hipMemcpy(tri, d_tri.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (t) HIP_TRY(hipMemcpy(t, d_t.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (pos) HIP_TRY(hipMemcpy(pos, d_pos.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    if (nrm) HIP_TRY(hipMemcpy(nrm, d_nrm.p, (size_t)n * 24, hipMemcpyDeviceToHost));
+    return RRT_OK;
+}
+
+int rrt_trace_rays(rrt_scene* s, const double* rays, int64_t n, int32_t* ent, int32_t* tri, double* t, double* pos,
+                   double* normal) {
+    return ray_query(s, rays, n, false, 0, 0, ent, tri, t, pos, normal, nullptr);
+}
+
+int rrt_cast_rays(rrt_scene* s, const double* rays, int64_t n, uint32_t max_bounce, uint32_t prune_zero_mix,
+                  double* color) {
+    if (!color) return fail(RRT_E_INVALID, "null colour output");
+    return ray_query(s, rays, n, true, max_bounce, prune_zero_mix, nullptr, nullptr, nullptr, nullptr, nullptr, color);
+}
+
+int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) {
+    rrt_scene* s = const_cast<rrt_scene*>(cs);
+    if (!s || !out) return fail(RRT_E_INVALID, "null argument");
+    if (!s->have_frame) return fail(RRT_E_STATE, "no frame rendered yet");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev_end));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
+    s->stats.gpu_ms = ms;
+    double trace = 0.0;
+    for (size_t i = 0; i < s->timed_used; ++i) {
+        float k = 0.f;
+        HIP_TRY(hipEventElapsedTime(&k, s->timed[i].a, s->timed[i].b));
+        trace += k;
+    }
+    s->stats.trace_kernel_ms = trace;
+    s->stats.trace_kernel_launches = (uint32_t)s->timed_used;
+    unsigned long long dev[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpy(dev, s->w_stats.p, sizeof(dev), hipMemcpyDeviceToHost));
+    s->stats.rays_traced = s->stats.primary_rays + dev[0];
+    s->stats.traversal_overflow = dev[1];
+    *out = s->stats;
+    return RRT_OK;
+}
+
+int rrt_mesh_tree_sizes(const rrt_scene* s, int entity, int32_t* n_nodes, int32_t* n_leaf_refs) {
+    if (!s || entity < 0 || entity >= (int)s->ents.size() || s->ents[(size_t)entity].kind != 1)
+        return fail(RRT_E_INVALID, "entity is not a mesh");
+    const rrt::KdTreeFlat& T = s->meshes[(size_t)s->ents[(size_t)entity].index]->tree;
+    if (n_nodes) *n_nodes = T.n_nodes();
+    if (n_leaf_refs) *n_leaf_refs = (int32_t)T.leaf_refs.size();
+    return RRT_OK;
+}
+
+int rrt_mesh_tree_export(const rrt_scene* s, int entity, double* boxes, double* split, int32_t* axis, int32_t* child,
+                         int32_t* ropes, int32_t* leaf_refs) {
+    if (!s || entity < 0 || entity >= (int)s->ents.size() || s->ents[(size_t)entity].kind != 1)
+        return fail(RRT_E_INVALID, "entity is not a mesh");
+    const rrt::KdTreeFlat& T = s->meshes[(size_t)s->ents[(size_t)entity].index]->tree;
+    if (boxes) std::memcpy(boxes, T.boxes.data(), T.boxes.size() * 8);
+    if (split) std::memcpy(split, T.split.data(), T.split.size() * 8);
+    if (axis) std::memcpy(axis, T.axis.data(), T.axis.size() * 4);
+    if (child) std::memcpy(child, T.child.data(), T.child.size() * 4);
+    if (ropes) std::memcpy(ropes, T.ropes.data(), T.ropes.size() * 4);
+    if (leaf_refs) std::memcpy(leaf_refs, T.leaf_refs.data(), T.leaf_refs.size() * 4);
+    return RRT_OK;
+}
+
+int rrt_selftest_math(int op, const double* a, const double* b, int64_t n, double* out) {
+    if (!a || !b || !out || n <= 0 || op < 0 || op > 3) return fail(RRT_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(g_device));
+    DevBuf da, db, dout;
+    HIP_TRY(da.upload(a, (size_t)n * 8));
+    HIP_TRY(db.upload(b, (size_t)n * 8));
+    HIP_TRY(dout.ensure((size_t)n * 8));
+    rrt::launch_selftest(op, da.as<double>(), db.as<double>(), n, dout.as<double>(), nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return RRT_OK;
+}
+
+void rrt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    rrt::philox4x32_10_host(ctr, key, out);
+}
+
+}  // extern "C"

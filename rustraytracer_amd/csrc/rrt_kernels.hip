@@ -1,0 +1,620 @@
+// =============================================================================
+// gfx950 (MI355X) kernels of the tracing hot path.  Built with
+// -ffp-contract=off: the reference is rustc-compiled f64 with no FMA
+// contraction and hit selection has to be bit-exact.
+//
+// Structure: a wavefront tracer.  One "path" = one pixel sample.  k_wave<true>
+// generates primary rays, k_wave<false> consumes the ray queue of the previous
+// bounce; each traces the world-level closest hit, shades, and either appends
+// the reflection ray to the next queue (wave-aggregated atomic) or folds the
+// path's per-bounce records back to front (tracer.rs:194-203 nests the
+// reflection inside the shading sum, so the fold order is fixed) and writes the
+// sample colour.  No host round trip inside a frame: bounce kernels read their
+// queue length from device memory and grid-stride over it.
+// =============================================================================
+#include <hip/hip_runtime.h>
+
+#include "rrt_device.h"
+
+namespace rrt {
+namespace {
+
+#define RRT_DEV __device__ __forceinline__
+
+struct V3 {
+    double x, y, z;
+};
+RRT_DEV V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+RRT_DEV V3 ld3(const double* p) { return V3{p[0], p[1], p[2]}; }
+RRT_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RRT_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RRT_DEV V3 operator*(V3 a, double s) { return V3{a.x * s, a.y * s, a.z * s}; }
+RRT_DEV V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+// cgmath 0.17: dot = (x*x' + y*y') + z*z'
+RRT_DEV double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RRT_DEV double mag2(V3 a) { return dot(a, a); }
+RRT_DEV V3 cross(V3 a, V3 b) {
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// cgmath normalize: v * (1 / |v|)
+RRT_DEV V3 normalize(V3 a) { return a * (1.0 / sqrt(mag2(a))); }
+RRT_DEV double comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+constexpr double kF64Max = 1.7976931348623157e308;
+
+// f64::powi with run-time exponent == compiler-rt __powidf2 (phong.rs:42)
+RRT_DEV double powi(double a, int b) {
+    const bool recip = b < 0;
+    double r = 1.0;
+    for (;;) {
+        if (b & 1) r *= a;
+        b /= 2;
+        if (b == 0) break;
+        a *= a;
+    }
+    return recip ? 1.0 / r : r;
+}
+
+// Rust `as u8` / `as u32`
+RRT_DEV uint32_t sat_u8(double v) {
+    if (!(v == v) || v <= 0.0) return 0u;
+    if (v >= 255.0) return 255u;
+    return (uint32_t)v;
+}
+RRT_DEV uint32_t sat_u32(double v) {
+    if (!(v == v) || v <= 0.0) return 0u;
+    if (v >= 4294967295.0) return 4294967295u;
+    return (uint32_t)v;
+}
+
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ---------------------------------------------------------------------------
+// AABB (src/geometry/aabb.rs)
+// ---------------------------------------------------------------------------
+RRT_DEV bool box_contains(V3 mn, V3 mx, V3 p) {   // aabb.rs:41-46
+    if (p.x > mx.x || p.x < mn.x) return false;
+    if (p.y > mx.y || p.y < mn.y) return false;
+    if (p.z > mx.z || p.z < mn.z) return false;
+    return true;
+}
+
+RRT_DEV double axis_time(double cand, double inv) {   // aabb.rs:76-80
+    const bool fin = fabs(inv) <= kF64Max;            // is_finite (false for NaN)
+    return fin ? cand * inv : (cand == 0. ? -1. : kF64Max);
+}
+
+// AABB::collide (aabb.rs:50-100), general form.  inv = 1/d per component.
+RRT_DEV bool box_collide(V3 mn, V3 mx, V3 o, V3 d, V3 inv, V3* pos) {
+    const bool inside = box_contains(mn, mx, o);
+    double cand[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double oi = comp(o, i), di = comp(d, i), lo = comp(mn, i), hi = comp(mx, i);
+        if (oi < lo) {
+            cand[i] = lo - oi;
+            if (di < 0.) return false;
+        } else if (oi > hi) {
+            cand[i] = hi - oi;
+            if (di > 0.) return false;
+        } else if (inside) {
+            cand[i] = (di > 0.) ? hi - oi : lo - oi;
+        } else {
+            cand[i] = -di;
+        }
+    }
+    const double t0 = axis_time(cand[0], inv.x), t1 = axis_time(cand[1], inv.y), t2 = axis_time(cand[2], inv.z);
+    if (inside) {
+        double t = t0;                 // min_by: first of equal minima
+        if (t1 < t) t = t1;
+        if (t2 < t) t = t2;
+        *pos = o + d * t;
+        return true;
+    }
+    double t = t0;                     // max_by: last of equal maxima
+    if (t1 >= t) t = t1;
+    if (t2 >= t) t = t2;
+    const V3 hp = o + d * t;
+    if (!box_contains(mn, mx, hp + mk(0.001, 0.001, 0.001))) return false;
+    *pos = hp;
+    return true;
+}
+
+// AABB::collide for an origin known to satisfy contains(): only the
+// `else if inside` arm of aabb.rs:56-72 can be taken, so this is the same
+// function, not an approximation.  (The traversal's point always satisfies
+// contains(leaf box): find_point only descends inside the box it tested.)
+RRT_DEV V3 box_exit(V3 mn, V3 mx, V3 o, V3 d, V3 inv) {
+    const double cx = (d.x > 0.) ? mx.x - o.x : mn.x - o.x;
+    const double cy = (d.y > 0.) ? mx.y - o.y : mn.y - o.y;
+    const double cz = (d.z > 0.) ? mx.z - o.z : mn.z - o.z;
+    const double t0 = axis_time(cx, inv.x), t1 = axis_time(cy, inv.y), t2 = axis_time(cz, inv.z);
+    double t = t0;
+    if (t1 < t) t = t1;
+    if (t2 < t) t = t2;
+    return o + d * t;
+}
+
+// ---------------------------------------------------------------------------
+// Triangle::collide (triangle.rs:25-58) on the pre-subtracted edges.
+// ---------------------------------------------------------------------------
+RRT_DEV bool tri_collide(const DTri* __restrict__ T, V3 o, V3 d, double* tout) {
+    const double EPS = 0.0000001;
+    const V3 e1 = ld3(T->e1), e2 = ld3(T->e2), v0 = ld3(T->v0);
+    const V3 h = cross(d, e2);
+    const double a = dot(e1, h);
+    if (a > -EPS && a < EPS) return false;
+    const double f = 1.0 / a;
+    const V3 s = o - v0;
+    const double u = f * dot(s, h);
+    if (!(0.0 <= u && u <= 1.0)) return false;
+    const V3 q = cross(s, e1);
+    const double v = f * dot(d, q);
+    if (v < 0.0 || u + v > 1.0) return false;
+    const double t = f * dot(e2, q);
+    if (t > EPS) {
+        *tout = t;
+        return true;
+    }
+    return false;
+}
+
+struct Hit {
+    bool hit;
+    int32_t tri;
+    int32_t mat;
+    double t;
+    V3 pos;
+    V3 normal;
+};
+
+// KDTree::find_point (kdtree.rs:23-33).  Returns leaf index or -1.
+RRT_DEV int32_t find_point(const DNode* __restrict__ nodes, int32_t at, V3 p) {
+    const DNode* n = nodes + at;
+    if (!box_contains(ld3(n->mn), ld3(n->mx), p)) return -1;
+    int32_t axis = n->axis;
+    while (axis >= 0) {
+        const double pv = comp(p, axis);
+        at = (pv >= n->split) ? n->c1 : n->c0;
+        n = nodes + at;
+        axis = n->axis;
+    }
+    return at;
+}
+
+// get_plane (kdtree.rs:237-244)
+RRT_DEV int get_plane(V3 p, V3 mn, V3 mx) {
+    if (p.x < mn.x) return 0;
+    if (p.y < mn.y) return 1;
+    if (p.z < mn.z) return 2;
+    if (p.x > mx.x) return 3;
+    if (p.y > mx.y) return 4;
+    return 5;
+}
+
+// KDTree::collide (kdtree.rs:192-235)
+RRT_DEV void mesh_collide(const DMesh* __restrict__ M, V3 o, V3 d, V3 inv, Hit* out, unsigned long long* stats) {
+    out->hit = false;
+    const DNode* __restrict__ nodes = M->nodes;
+    V3 point;
+    if (!box_collide(ld3(nodes[0].mn), ld3(nodes[0].mx), o, d, inv, &point)) return;
+    point = point + d * 0.01;
+    int32_t leaf = find_point(nodes, 0, point);
+    const int32_t* __restrict__ refs = M->leaf_refs;
+    const DTri* __restrict__ tris = M->tris;
+    uint32_t visits = 0;
+    while (leaf >= 0) {
+        if (++visits > kMaxLeafVisits) {
+            atomicAdd(&stats[1], 1ull);
+            return;
+        }
+        const DNode* n = nodes + leaf;
+        const int32_t first = n->c0, count = n->c1;
+        double best = kF64Max, best_t = 0.0;
+        int32_t best_tri = -1;
+        V3 best_pos = mk(0., 0., 0.);
+        for (int32_t k = 0; k < count; ++k) {
+            const int32_t id = refs[first + k];
+            double t;
+            if (tri_collide(tris + id, o, d, &t)) {
+                const V3 pos = o + d * t;
+                const double dist = mag2(pos - o);
+                if (dist < best) {
+                    best = dist; best_t = t; best_tri = id; best_pos = pos;
+                }
+            }
+        }
+        if (best_tri >= 0) {
+            out->hit = true; out->tri = best_tri; out->t = best_t; out->pos = best_pos;
+            out->normal = ld3(M->normals + 3 * (size_t)best_tri);
+            out->mat = M->material;
+            return;
+        }
+        const V3 mn = ld3(n->mn), mx = ld3(n->mx);
+        point = box_exit(mn, mx, point, d, inv) + d * 0.001;
+        const int32_t nb = n->rope[get_plane(point, mn, mx)];
+        if (nb < 0) return;
+        leaf = find_point(nodes, nb, point);
+    }
+}
+
+// Sphere::collide (sphere.rs:28-47)
+RRT_DEV void sphere_collide(const DSphere* __restrict__ S, V3 o, V3 d, Hit* out) {
+    out->hit = false;
+    const V3 c = ld3(S->c);
+    const V3 l = c - o;
+    const double tca = dot(l, d);
+    if (tca < 0.0) return;
+    const double d2 = mag2(l) - tca * tca;
+    const double r2 = S->r2;
+    if (d2 > r2) return;
+    const double thc = sqrt(r2 - d2);
+    const double t = tca - thc;
+    out->hit = true; out->tri = -1; out->t = t; out->mat = S->material;
+    out->pos = o + d * t;
+    out->normal = normalize(out->pos - c);
+}
+
+// The entity loop of RayTracer::cast (tracer.rs:178-190)
+RRT_DEV int32_t closest_hit(const DScene& sc, V3 o, V3 d, Hit* best, unsigned long long* stats) {
+    const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);   // aabb.rs:74, same for every box test of this ray
+    double min_d = kF64Max;
+    int32_t best_ent = -1;
+    best->hit = false; best->tri = -1; best->t = 0.0; best->mat = -1;
+    best->pos = mk(0., 0., 0.); best->normal = mk(0., 0., 0.);
+    for (int32_t e = 0; e < sc.n_ents; ++e) {
+        const DEntity ent = sc.ents[e];
+        Hit h;
+        if (ent.kind == 0) sphere_collide(sc.spheres + ent.index, o, d, &h);
+        else mesh_collide(sc.meshes + ent.index, o, d, inv, &h, stats);
+        if (h.hit) {
+            const double dist = mag2(h.pos - o);
+            if (dist < min_d) {
+                min_d = dist; *best = h; best_ent = e;
+            }
+        }
+    }
+    return best_ent;
+}
+
+// cubemap() + CubemapBehavior::compute (cubemap.rs:84-164, 56-77)
+RRT_DEV V3 sky_color(const DScene& sc, V3 dir) {
+    const double x = dir.x, y = dir.y, z = dir.z;
+    const double ax = fabs(x), ay = fabs(y), az = fabs(z);
+    const bool xp = x > 0.0, yp = y > 0.0, zp = z > 0.0;
+    double max_axis = 0.0, uc = 0.0, vc = 0.0;
+    uint32_t idx = 0;
+    if (xp && ax >= ay && ax >= az) { max_axis = ax; uc = -z; vc = y; idx = 0; }
+    if (!xp && ax >= ay && ax >= az) { max_axis = ax; uc = z; vc = y; idx = 1; }
+    if (yp && ay >= ax && ay >= az) { max_axis = ay; uc = x; vc = -z; idx = 2; }
+    if (!yp && ay >= ax && ay >= az) { max_axis = ay; uc = x; vc = z; idx = 3; }
+    if (zp && az >= ax && az >= ay) { max_axis = az; uc = x; vc = y; idx = 4; }
+    if (!zp && az >= ax && az >= ay) { max_axis = az; uc = -x; vc = y; idx = 5; }
+    const double u = 0.5 * (uc / max_axis + 1.0);
+    const double v = 0.5 * (vc / max_axis + 1.0);
+    const uint32_t w = sc.sky_w[idx], hgt = sc.sky_h[idx];
+    uint32_t px = sat_u32(u * (double)w), py = sat_u32(v * (double)hgt);
+    if (px >= w) px = w - 1;
+    if (py >= hgt) py = hgt - 1;
+    const uint8_t* p = sc.sky[idx] + ((size_t)py * w + px) * 3;
+    return mk((double)p[0] / 255.0, (double)p[1] / 255.0, (double)p[2] / 255.0);
+}
+
+// Direct terms of a hit (tracer.rs:194-202 with lambert.rs:22-45, phong.rs:25-47):
+//   A  = color*ambient + Lambert*mixL      Pm = Phong*mixP
+RRT_DEV void shade_direct(const DScene& sc, const DMaterial& m, V3 d, V3 normal, V3* A, V3* Pm) {
+    const V3 color = ld3(m.color);
+    V3 fin = color * sc.ambient;
+    const V3 L = ld3(sc.light_dir);
+    const bool visible = sc.has_light && (dot(normal, L) < 0.);   // lighting.rs:43-45
+    V3 lam = mk(0., 0., 0.), ph = mk(0., 0., 0.);
+    if (visible) {
+        double power = sc.light_intensity * (m.albedo / 3.14159265358979323846) * -dot(normal, L);
+        power = fmax(power, 0.);
+        lam = lam + color * power;
+        const V3 bis = normalize(neg(L) - d);
+        const double pw = sc.light_intensity * powi(fmax(dot(bis, normal), 0.), m.alpha);
+        ph = ph + ld3(sc.light_color) * pw;
+    }
+    *A = fin + lam * m.mixL;
+    *Pm = ph * m.mixP;
+}
+
+// reflection.rs:29-33, 42-44
+RRT_DEV void reflect_ray(V3 pos, V3 normal, V3 d, V3* ro, V3* rd) {
+    *ro = pos + normal * 0.3;
+    *rd = normalize(d - (normal * dot(normal, d)) * 2.0);
+}
+
+// Wave-aggregated queue append: one atomic per wave.
+RRT_DEV uint32_t queue_slot(uint32_t* counter, bool want) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return 0u;
+    const uint32_t lane = __lane_id();
+    const uint32_t n = (uint32_t)__popcll(mask);
+    const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, n);
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    return base + before;
+}
+
+// tracer.rs:84-110, 126-131 with the sub-pixel jitter extension.
+RRT_DEV void primary_ray(const DFrame& fr, uint32_t x, uint32_t y, uint32_t sample, V3* o, V3* d) {
+    double jx = 0.0, jy = 0.0;
+    if (sample != 0u) {
+        uint32_t r[4];
+        philox4x32_10(y * fr.width + x, sample, 0u, 0u, fr.seed_lo, fr.seed_hi, r);
+        jx = (double)r[0] * (1.0 / 4294967296.0);
+        jy = (double)r[1] * (1.0 / 4294967296.0);
+    }
+    const V3 eye = mk(fr.cam.eye[0], fr.cam.eye[1], fr.cam.eye[2]);
+    const V3 lens_pos = eye + mk(0.0, 0.0, fr.cam.lens_z);
+    const V3 ll = lens_pos - mk(fr.cam.lens_w / 2.0, fr.cam.lens_h / 2.0, 0.0);
+    const V3 lh = mk(fr.cam.lens_w, 0.0, 0.0), lv = mk(0.0, fr.cam.lens_h, 0.0);
+    const double fx = ((double)x + jx) / (double)fr.width;
+    const double fy = ((double)y + jy) / (double)fr.height;
+    const V3 lp = (ll + lh * fx) + lv * fy;
+    *o = eye;
+    *d = normalize(lp - eye);
+}
+
+RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y) {
+    const uint32_t slot = lp >> 8, in = lp & 255u;
+    const uint32_t tile = slot * fr.tile_world + fr.tile_rank;
+    if (tile >= fr.tiles_x * fr.tiles_y) return false;
+    const uint32_t tx = tile % fr.tiles_x, ty = tile / fr.tiles_x;
+    *x = tx * RRT_TILE_W + (in & 31u);
+    *y = ty * RRT_TILE_H + (in >> 5);
+    return *x < fr.width && *y < fr.height;
+}
+
+// One cast() (tracer.rs:177-211) of path `path` at depth `bounce`.
+template <bool PRIMARY>
+RRT_DEV void process_ray(const DScene& sc, const DWork& wk, const DFrame& fr, bool active, uint32_t path, V3 o, V3 d,
+                         uint32_t bounce, int32_t* d_ids, double* d_t, uint32_t pixel, bool aov) {
+    const uint64_t P = wk.cap;
+    bool cont = false;
+    V3 ro = mk(0., 0., 0.), rd = mk(0., 0., 0.);
+    if (active) {
+        Hit h;
+        const int32_t ent = closest_hit(sc, o, d, &h, wk.stats);
+        if (PRIMARY && aov) {
+            if (d_ids) { d_ids[2 * (size_t)pixel] = ent; d_ids[2 * (size_t)pixel + 1] = h.tri; }
+            if (d_t) d_t[pixel] = h.hit ? h.t : 0.0;
+        }
+        V3 col;
+        if (h.hit) {
+            const DMaterial m = sc.mats[h.mat];
+            V3 A, Pm;
+            shade_direct(sc, m, d, h.normal, &A, &Pm);
+            cont = !(bounce > fr.max_bounce) && !(fr.prune && m.mixR == 0.0);
+            if (cont) {
+                const size_t r = (size_t)bounce * 3 * P + path;
+                wk.recA[r] = A.x; wk.recA[r + P] = A.y; wk.recA[r + 2 * P] = A.z;
+                wk.recP[r] = Pm.x; wk.recP[r + P] = Pm.y; wk.recP[r + 2 * P] = Pm.z;
+                wk.recR[(size_t)bounce * P + path] = m.mixR;
+                reflect_ray(h.pos, h.normal, d, &ro, &rd);
+            } else {
+                col = A + Pm;   // Reflection returned None (reflection.rs:26-28) or was pruned
+            }
+        } else {
+            col = sky_color(sc, d);
+        }
+        if (!cont) {
+            // fold the enclosing casts: final = (A + R*mixR) + Pm  (tracer.rs:194-202)
+            for (uint32_t k = bounce; k-- > 0;) {
+                const size_t r = (size_t)k * 3 * P + path;
+                const double mr = wk.recR[(size_t)k * P + path];
+                const V3 A = mk(wk.recA[r], wk.recA[r + P], wk.recA[r + 2 * P]);
+                const V3 Pm = mk(wk.recP[r], wk.recP[r + P], wk.recP[r + 2 * P]);
+                col = (A + col * mr) + Pm;
+            }
+            wk.samp[path] = col.x; wk.samp[path + P] = col.y; wk.samp[path + 2 * P] = col.z;
+        }
+    }
+    const uint32_t slot = queue_slot(&wk.q_count[bounce + 1], cont);
+    if (cont) {
+        const DQueue& q = wk.q[(bounce + 1) & 1];
+        q.o[slot] = ro.x; q.o[slot + P] = ro.y; q.o[slot + 2 * P] = ro.z;
+        q.d[slot] = rd.x; q.d[slot + P] = rd.y; q.d[slot + 2 * P] = rd.z;
+        q.path[slot] = path;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
+    const uint32_t path = blockIdx.x * 256u + threadIdx.x;   // grid covers ns * npx_local exactly
+    const uint32_t s_local = path / fr.npx_local, lp = path - s_local * fr.npx_local;
+    uint32_t x = 0, y = 0;
+    const bool active = local_pixel(fr, lp, &x, &y);
+    const uint32_t sample = fr.s0 + s_local;
+    V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+    if (active) primary_ray(fr, x, y, sample, &o, &d);
+    process_ray<true>(sc, wk, fr, active, path, o, d, 0u, d_ids, d_t, y * fr.width + x, sample == 0u);
+}
+
+__global__ __launch_bounds__(256) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
+    const uint32_t count = wk.q_count[bounce];
+    const uint32_t stride = gridDim.x * 256u;
+    const uint64_t P = wk.cap;
+    const DQueue& q = wk.q[bounce & 1];
+    // every lane of a wave runs the same number of iterations (queue_slot uses wave-wide ops)
+    const uint32_t rounds = (count + stride - 1) / stride;
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    for (uint32_t r = 0; r < rounds; ++r, i += stride) {
+        const bool active = i < count;
+        V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+        uint32_t path = 0;
+        if (active) {
+            o = mk(q.o[i], q.o[i + P], q.o[i + 2 * P]);
+            d = mk(q.d[i], q.d[i + P], q.d[i + 2 * P]);
+            path = q.path[i];
+        }
+        process_ray<false>(sc, wk, fr, active, path, o, d, bounce, nullptr, nullptr, 0u, false);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wk.stats[0], (unsigned long long)count);
+}
+
+// accum[lp] (+)= sum over this batch's samples, in sample order.
+__global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr) {
+    const uint32_t lp = blockIdx.x * 256u + threadIdx.x;
+    if (lp >= fr.npx_local) return;
+    const uint64_t P = wk.cap;
+    const uint32_t N = fr.npx_local;
+    V3 acc = mk(0., 0., 0.);
+    if (fr.s0 != 0u) acc = mk(wk.accum[lp], wk.accum[lp + N], wk.accum[lp + 2 * (size_t)N]);
+    for (uint32_t s = 0; s < fr.ns; ++s) {
+        const size_t p = (size_t)s * N + lp;
+        const V3 c = mk(wk.samp[p], wk.samp[p + P], wk.samp[p + 2 * P]);
+        acc = (fr.s0 + s == 0u) ? c : acc + c;
+    }
+    wk.accum[lp] = acc.x; wk.accum[lp + N] = acc.y; wk.accum[lp + 2 * (size_t)N] = acc.z;
+}
+
+// mean = sum / spp ; vec_rgb (common.rs:75-81)
+__global__ __launch_bounds__(256) void k_resolve(DWork wk, DFrame fr, uint8_t* d_rgb8, double* d_color) {
+    const uint32_t lp = blockIdx.x * 256u + threadIdx.x;
+    if (lp >= fr.npx_local) return;
+    const uint32_t N = fr.npx_local;
+    uint32_t x = 0, y = 0;
+    const bool valid = local_pixel(fr, lp, &x, &y);
+    const double n = (double)fr.spp;
+    V3 mean = mk(0., 0., 0.);
+    if (valid) mean = mk(wk.accum[lp] / n, wk.accum[lp + N] / n, wk.accum[lp + 2 * (size_t)N] / n);
+    const uint32_t r = sat_u8(mean.x * 255.0), g = sat_u8(mean.y * 255.0), b = sat_u8(mean.z * 255.0);
+    if (fr.tile_world == 1u) {
+        if (!valid) return;
+        const size_t px = (size_t)y * fr.width + x;
+        if (d_rgb8) { d_rgb8[3 * px] = (uint8_t)r; d_rgb8[3 * px + 1] = (uint8_t)g; d_rgb8[3 * px + 2] = (uint8_t)b; }
+        if (d_color) { d_color[3 * px] = mean.x; d_color[3 * px + 1] = mean.y; d_color[3 * px + 2] = mean.z; }
+    } else if (d_rgb8) {
+        d_rgb8[3 * (size_t)lp] = (uint8_t)r; d_rgb8[3 * (size_t)lp + 1] = (uint8_t)g; d_rgb8[3 * (size_t)lp + 2] = (uint8_t)b;
+    }
+}
+
+// [world][slots][8][32][3] -> row-major [H][W][3]
+__global__ __launch_bounds__(256) void k_assemble(const uint8_t* g, uint32_t w, uint32_t h, uint32_t world,
+                                                  uint32_t slots, uint32_t tiles_x, uint8_t* out) {
+    const uint32_t px = blockIdx.x * 256u + threadIdx.x;
+    if (px >= w * h) return;
+    const uint32_t x = px % w, y = px / w;
+    const uint32_t tile = (y / RRT_TILE_H) * tiles_x + (x / RRT_TILE_W);
+    const uint32_t rank = tile % world, slot = tile / world;
+    const size_t src = (((size_t)rank * slots + slot) * 256u + (y % RRT_TILE_H) * RRT_TILE_W + (x % RRT_TILE_W)) * 3;
+    out[3 * (size_t)px] = g[src]; out[3 * (size_t)px + 1] = g[src + 1]; out[3 * (size_t)px + 2] = g[src + 2];
+}
+
+__global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* rays, int64_t n, int32_t* ent,
+                                                    int32_t* tri, double* t, double* pos, double* nrm,
+                                                    unsigned long long* stats) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
+    Hit h;
+    const int32_t e = closest_hit(sc, o, d, &h, stats);
+    if (ent) ent[i] = e;
+    if (tri) tri[i] = h.tri;
+    if (t) t[i] = h.hit ? h.t : 0.0;
+    if (pos) { pos[3 * i] = h.pos.x; pos[3 * i + 1] = h.pos.y; pos[3 * i + 2] = h.pos.z; }
+    if (nrm) { nrm[3 * i] = h.normal.x; nrm[3 * i + 1] = h.normal.y; nrm[3 * i + 2] = h.normal.z; }
+}
+
+// cast() as one thread per ray with a private record stack (test / probe API).
+__global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays, int64_t n, uint32_t max_bounce,
+                                                   uint32_t prune, double* color, unsigned long long* stats) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
+    V3 sA[kMaxLevels], sP[kMaxLevels];
+    double sR[kMaxLevels];
+    uint32_t bounce = 0;
+    V3 col;
+    for (;;) {
+        Hit h;
+        closest_hit(sc, o, d, &h, stats);
+        if (!h.hit) { col = sky_color(sc, d); break; }
+        const DMaterial m = sc.mats[h.mat];
+        V3 A, Pm;
+        shade_direct(sc, m, d, h.normal, &A, &Pm);
+        const bool cont = !(bounce > max_bounce) && !(prune && m.mixR == 0.0);
+        if (!cont) { col = A + Pm; break; }
+        sA[bounce] = A; sP[bounce] = Pm; sR[bounce] = m.mixR;
+        V3 ro, rd;
+        reflect_ray(h.pos, h.normal, d, &ro, &rd);
+        o = ro; d = rd; ++bounce;
+    }
+    for (uint32_t k = bounce; k-- > 0;) col = (sA[k] + col * sR[k]) + sP[k];
+    color[3 * i] = col.x; color[3 * i + 1] = col.y; color[3 * i + 2] = col.z;
+}
+
+__global__ void k_selftest(int op, const double* a, const double* b, int64_t n, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = a[i], y = b[i];
+    double r;
+    if (op == 0) r = x / y;
+    else if (op == 1) r = sqrt(x);
+    else if (op == 2) r = x * y + y;
+    else r = powi(x, (int)y);
+    out[i] = r;
+}
+
+inline uint32_t bounce_grid() { return 256u * 8u; }   // 256 CUs x 8 blocks of 256 threads
+
+}  // namespace
+
+void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
+    const uint64_t paths = (uint64_t)fr.ns * fr.npx_local;
+    hipLaunchKernelGGL(k_wave_primary, dim3((uint32_t)(paths / 256)), dim3(256), 0, (hipStream_t)stream, sc, wk, fr,
+                       d_ids, d_t);
+}
+void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream) {
+    hipLaunchKernelGGL(k_wave_bounce, dim3(bounce_grid()), dim3(256), 0, (hipStream_t)stream, sc, wk, fr, bounce);
+}
+void launch_accumulate(const DWork& wk, const DFrame& fr, void* stream) {
+    hipLaunchKernelGGL(k_accumulate, dim3(fr.npx_local / 256), dim3(256), 0, (hipStream_t)stream, wk, fr);
+}
+void launch_resolve(const DWork& wk, const DFrame& fr, uint8_t* d_rgb8, double* d_color, void* stream) {
+    hipLaunchKernelGGL(k_resolve, dim3(fr.npx_local / 256), dim3(256), 0, (hipStream_t)stream, wk, fr, d_rgb8, d_color);
+}
+void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream) {
+    const uint32_t tiles_x = (w + RRT_TILE_W - 1) / RRT_TILE_W, tiles_y = (h + RRT_TILE_H - 1) / RRT_TILE_H;
+    const uint32_t slots = (tiles_x * tiles_y + world - 1) / world;
+    const uint32_t n = w * h;
+    hipLaunchKernelGGL(k_assemble, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_gathered, w, h, world,
+                       slots, tiles_x, d_rgb8);
+}
+void launch_trace_rays(const DScene& sc, const double* d_rays, int64_t n, int32_t* ent, int32_t* tri, double* t,
+                       double* pos, double* nrm, unsigned long long* stats, void* stream) {
+    hipLaunchKernelGGL(k_trace_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sc, d_rays,
+                       n, ent, tri, t, pos, nrm, stats);
+}
+void launch_cast_rays(const DScene& sc, const double* d_rays, int64_t n, uint32_t max_bounce, uint32_t prune,
+                      double* color, unsigned long long* stats, void* stream) {
+    hipLaunchKernelGGL(k_cast_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sc, d_rays,
+                       n, max_bounce, prune, color, stats);
+}
+void launch_selftest(int op, const double* a, const double* b, int64_t n, double* out, void* stream) {
+    hipLaunchKernelGGL(k_selftest, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, n,
+                       out);
+}
+void philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+}  // namespace rrt

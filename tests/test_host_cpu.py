@@ -1,0 +1,146 @@
+"""CPU-side checks of the product's host layer (no GPU compute calls):
+the C-ABI library loads and exports every declared symbol, its C++ asset
+loaders agree with the oracle-side numpy/PIL loaders, and its kd-tree builder
+emits the same flat tree as the oracle's restatement of kdtree.rs."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(H):
+    from rustraytracer_amd import binding as B
+    declared = set()
+    for hdr in ("rrt.h", "rrt_host.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(rrt_[a-z0-9_]+)\s*\(", text))
+    assert declared, "no declarations parsed"
+    assert declared == set(B.EXPORTS)
+    for name in declared:
+        assert hasattr(B.lib, name), name
+    assert b"gfx950" in B.lib.rrt_version()
+
+
+def test_loaders_agree_with_oracle_side(H, O, scenes):
+    for obj, pos, sc in (("ufo_fix.obj", (0, 30, 70), (1, -1, 1)), ("cube.obj", (0, 0, 12), (2, 2, 2))):
+        p = os.path.join(scenes.ASSETS, "obj", obj)
+        vo, no = O.load_model(p, pos, sc)
+        vp, np_ = H.loaders.load_model(p, pos, sc)
+        assert np.array_equal(vo, vp) and np.array_equal(no, np_)
+    for cm in ("sky", "hd_blue_sunset"):   # RGB, palette ('sky/up.png') and RGBA PNGs
+        a = O.load_cubemap(os.path.join(scenes.ASSETS, "cubemaps", cm))
+        b = H.loaders.load_cubemap(os.path.join(scenes.ASSETS, "cubemaps", cm))
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_png_round_trip(H, tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    p = str(tmp_path / "x.png")
+    H.loaders.save_png(p, img)
+    assert np.array_equal(H.loaders.load_png(p), img)
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(p)), img)
+
+
+def test_loader_errors_are_codes_not_aborts(H, tmp_path):
+    from rustraytracer_amd import binding as B
+    with pytest.raises(B.RrtError, match="cannot open"):
+        H.loaders.load_model(str(tmp_path / "missing.obj"), (0, 0, 0), (1, 1, 1))
+    quad = tmp_path / "quad.obj"
+    quad.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1 4//1\n")
+    with pytest.raises(B.RrtError, match="not a triangle"):     # obj-rs refuses untriangulated models
+        H.loaders.load_model(str(quad), (0, 0, 0), (1, 1, 1))
+    nonorm = tmp_path / "nonorm.obj"
+    nonorm.write_text("v 0 0 0\nv 1 0 0\nv 1 1 0\nf 1 2 3\nf 1 2 3\n")
+    with pytest.raises(B.RrtError, match="normal"):
+        H.loaders.load_model(str(nonorm), (0, 0, 0), (1, 1, 1))
+    with pytest.raises(B.RrtError):
+        H.loaders.load_png(os.path.join(ROOT, "assets", "obj", "cube.obj"))
+
+
+def test_scene_argument_errors(H):
+    from rustraytracer_amd import binding as B
+    w = H.World()
+    with pytest.raises(B.RrtError, match="unknown material"):
+        w.add_sphere((0, 0, 0), 1.0, 3)
+    m = w.add_material((1, 1, 1), 1, 1, 0, 0, 20)
+    assert m == 0 and w.add_sphere((0, 0, 5), 1.0, m) == 0
+    with pytest.raises(B.RrtError, match="not a mesh"):
+        w.tree(0)
+    with pytest.raises(B.RrtError, match="bad face"):
+        B.check(B.lib.rrt_set_sky_face(w.h, 7, np.zeros(3, np.uint8).ctypes.data, 1, 1))
+    assert H.tile_slots(1920, 1080, 1) == 60 * 135
+    assert H.tile_slots(1920, 1080, 8) == (60 * 135 + 7) // 8
+    assert H.tile_slots(33, 9, 2) == 2
+
+
+def _trees_equal(a, b):
+    return all(np.array_equal(a[k], b[k]) for k in a)
+
+
+def test_kd_tree_identical_to_oracle_ufo_and_cube(H, O, scenes):
+    for fn in (scenes.main_rs_scene, scenes.cfg1_scene):
+        so = fn(O.OracleScene(), O)
+        sp = fn(H.World(), H.loaders)
+        to, tp = so.tree(0), sp.tree(0)
+        assert _trees_equal(to, tp)
+    # structural facts of the UFO tree
+    leaf = to["axis"] < 0 if fn is scenes.main_rs_scene else None
+
+
+def _random_mesh(rng, n, quant=None, spread=20.0, size=1.5):
+    c = rng.uniform(-spread, spread, (n, 1, 3)) + np.array([0, 0, 60.0])
+    v = c + rng.uniform(-size, size, (n, 3, 3))
+    if quant:                      # many tied bbox-min keys, like a modelled mesh
+        v = np.round(v / quant) * quant
+    nrm = np.cross(v[:, 1] - v[:, 0], v[:, 2] - v[:, 0])
+    nrm += (np.linalg.norm(nrm, axis=1, keepdims=True) == 0) * np.array([0, 0, 1.0])
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return v, nrm
+
+
+@pytest.mark.parametrize("n,quant,seed", [(5, None, 0), (6, 1.0, 1), (64, None, 2), (300, 0.5, 3),
+                                          (5000, 1.0, 4), (5000, None, 5), (40000, 2.0, 6)])
+def test_kd_tree_identical_to_oracle_random(H, O, n, quant, seed):
+    """The sort's tie order, block partition (>256 items), pattern breaking and
+    the no-progress leaf rule all get exercised by quantised meshes."""
+    rng = np.random.default_rng(seed)
+    v, nrm = _random_mesh(rng, n, quant)
+    so, sp = O.OracleScene(), H.World()
+    for s in (so, sp):
+        m = s.add_material((0.5, 0.5, 0.5), 1.0, 1.0, 0.0, 0.3, 20)
+        s.add_mesh(v, nrm, m)
+    to, tp = so.tree(0), sp.tree(0)
+    assert _trees_equal(to, tp)
+    leaf = to["axis"] < 0
+    # every triangle is referenced at least once; rope targets are valid nodes
+    assert set(np.unique(to["leaf_refs"])) == set(range(n))
+    r = to["ropes"][leaf]
+    assert r.min() >= -1 and r.max() < len(to["axis"])
+    assert (to["ropes"][~leaf] == -1).all()
+
+
+def test_rope_faces_touch(H):
+    """A leaf's rope through face i leads to a node whose box touches that face."""
+    rng = np.random.default_rng(9)
+    v, nrm = _random_mesh(rng, 2000)
+    w = H.World()
+    w.add_mesh(v, nrm, w.add_material((1, 1, 1), 1, 1, 0, 0, 20))
+    t = w.tree(0)
+    root = t["boxes"][0]
+    for i in np.nonzero(t["axis"] < 0)[0]:
+        for k in range(6):
+            nb = t["ropes"][i, k]
+            a = k % 3
+            mine = t["boxes"][i, a] if k < 3 else t["boxes"][i, 3 + a]
+            if nb < 0:
+                assert mine == (root[a] if k < 3 else root[3 + a])
+            else:
+                theirs = t["boxes"][nb, 3 + a] if k < 3 else t["boxes"][nb, a]
+                assert theirs == mine
