@@ -48,6 +48,16 @@ EXPORTS = [
 
 
 def _load():
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7
+    # (same SONAME as /opt/rocm's).  Whichever is loaded first serves both, and
+    # torch does not find the GPU on a runtime it did not bring.  So when torch is
+    # importable it is loaded first and librrt.so binds to torch's runtime; the
+    # library itself has no torch dependency (RRT_NO_TORCH=1 skips this).
+    if os.environ.get("RRT_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "librrt.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "

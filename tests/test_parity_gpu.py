@@ -39,8 +39,9 @@ def test_device_arithmetic_is_ieee(H):
     with np.errstate(all="ignore"):
         B.check(B.lib.rrt_selftest_math(0, a.ctypes.data, b.ctypes.data, a.size, out.ctypes.data))
         assert np.array_equal(out, a / b, equal_nan=True)
-        B.check(B.lib.rrt_selftest_math(1, np.abs(a).ctypes.data, b.ctypes.data, a.size, out.ctypes.data))
-        assert np.array_equal(out, np.sqrt(np.abs(a)))
+        aa = np.abs(a)     # named: a temporary's buffer would be freed before the call
+        B.check(B.lib.rrt_selftest_math(1, aa.ctypes.data, b.ctypes.data, a.size, out.ctypes.data))
+        assert np.array_equal(out, np.sqrt(aa))
         B.check(B.lib.rrt_selftest_math(2, a.ctypes.data, b.ctypes.data, a.size, out.ctypes.data))
         assert np.array_equal(out, (a * b) + b, equal_nan=True)
     x = rng.uniform(0, 1.2, 1000); e = np.full(1000, 20.0)
