@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Benchmark of the tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path (primary rays -> closest hit ->
+shading -> reflection bounces -> sky lookup -> accumulate -> quantise, and for
+N > 1 the framebuffer gather over RCCL + de-interleave) over BASELINE.json's
+configs[1]: the main.rs world (ufo_fix.obj kd-tree + 2 spheres) under the
+blue_sunset cubemap at 1920x1080, 16 spp.  The scene is resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line.
+
+Metric: Mrays/s, whole job.  A ray = one world-level closest-hit query (one
+`RayTracer::cast`, src/tracer.rs:177) actually executed on the GPU, with
+reference semantics (prune_zero_mix = 0: the reflection ray is cast even when
+its mix is 0.0, as src/tracer.rs:195-201 does).
+
+Multi-GPU (weak scaling, the default): the image's 32x8 tiles are dealt
+round-robin over the ranks and the frame is rendered at 16*N spp, so each GPU
+keeps one 1080p/16spp frame's worth of samples per step; one all-gather of the
+compact RGB8 tile buffers (1080p: 6.2 MB in total) and a de-interleave on every
+rank end the step.  --scaling strong keeps 16 spp in total instead.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (first: brings the process's HIP runtime)
+import torch.distributed as dist  # noqa: E402
+
+W, H, SPP = 1920, 1080, 16
+
+# Algorithmic work per ray for the roofline (DESIGN.md "Measurement"): sizes of the
+# device layout in csrc/rrt_device.h and flop counts of SURVEY §8(d).
+S_NODE, S_LEAF, S_TRI, S_HITN = 16, 88, 76, 24     # bytes: interior step / leaf header / triangle test / winner's normal
+F_TRI, F_BOX, F_NODE, F_SHADE, F_SPHERE = 53, 30, 1, 120, 25
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_F64_TFLOPS = 78.6      # vector FP64 (FMA-counted; this path may not contract FMAs)
+
+
+def cpu_leg(n_threads, row_stride=1):
+    """Times the CPU oracle (a port of the reference, oracle/) on a bounded,
+    strided-row sample of the same workload and counts the per-ray traversal
+    work that prices the roofline."""
+    import numpy as np
+    from oracle import oracle as O
+    from rustraytracer_amd import scenes
+    cpu = scenes.cfg2_scene(O.OracleScene(), O)
+    cpu.render(W, H, spp=1, n_threads=n_threads, y0=0, y1=64, want=())            # warm
+    t0 = time.perf_counter()
+    out = cpu.render(W, H, spp=SPP, seed=0, n_threads=n_threads, y0=3, row_stride=row_stride, want=())
+    dt = time.perf_counter() - t0
+    c = dict(zip(O.COUNTER_NAMES, (int(x) for x in out["counters"])))
+    rows = len(range(3, H, row_stride))
+    # per-primary-ray traversal work: closest-hit of the sample-0 primary rays of those rows
+    import ctypes as C
+    st = O.Settings(W, H, 1, 2, 0, 0, 1)
+    cam = O.default_camera()
+    ys = list(range(3, H, row_stride))
+    rays = np.zeros((len(ys) * W, 6))
+    r = np.zeros(6)
+    L = O.lib()
+    k = 0
+    for y in ys[::32]:
+        for x in range(W):
+            L.orc_primary_ray(C.byref(cam), C.byref(st), x, y, 0, r.ctypes.data)
+            rays[k] = r
+            k += 1
+    pc = dict(zip(O.COUNTER_NAMES, (int(x) for x in cpu.trace_rays(rays[:k])["counters"])))
+    return {
+        "value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": n_threads, "kind": "port",
+        "sample": "rows 3..%d step %d of the %dx%d frame (%d rows), %d spp, %d rays in %.2f s; C++ f64 restatement "
+                  "of the reference, rows handed to threads dynamically (no per-hit Material clone: optimistic "
+                  "for the Rust binary)" % (H - 1, row_stride, W, H, rows, SPP, c["rays"], dt),
+    }, c, pc, k
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--prune", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from rustraytracer_amd import host as Hst, scenes
+    scene = scenes.cfg2_scene(Hst.World(device=local_rank), Hst.loaders)
+    scene.commit()                                   # scene resident in HBM before timing
+    spp = SPP * world if args.scaling == "weak" else SPP
+    st = Hst.make_settings(W, H, spp=spp, max_bounce=2, seed=0, prune_zero_mix=args.prune,
+                           tile_rank=rank, tile_world=world)
+    frame = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
+    if world > 1:
+        slots = Hst.tile_slots(W, H, world)
+        local = torch.empty((slots, 8, 32, 3), dtype=torch.uint8, device=dev)
+        gathered = torch.empty((world, slots, 8, 32, 3), dtype=torch.uint8, device=dev)
+
+    def step():
+        stream = torch.cuda.current_stream().cuda_stream
+        if world == 1:
+            scene.render_device(st, frame.data_ptr(), stream=stream)
+        else:
+            scene.render_device(st, local.data_ptr(), stream=stream)
+            dist.all_gather_into_tensor(gathered, local)
+            Hst.assemble_tiles(gathered.data_ptr(), W, H, world, frame.data_ptr(), stream=stream)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    prim_ms = bnc_ms = 0.0
+    prim_n = bnc_n = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = scene.stats()                             # per-kernel hipEvent timings of the last timed step
+    prim_ms, prim_n = stats["primary_kernel_ms"], stats["primary_kernel_launches"]
+    bnc_ms, bnc_n = stats["bounce_kernel_ms"], stats["bounce_kernel_launches"]
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    rays = torch.tensor([stats["rays_traced"], stats["paths"], stats["traversal_overflow"]], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    dt = float(t.item())
+    rays_step, paths_step, overflow = (int(x) for x in rays.tolist())
+
+    if rank == 0:
+        value = rays_step * args.steps / dt / 1e6
+        line = {
+            "metric": "Mrays/s (node) ufo.obj kd-tree 1080p", "value": value, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic camera rays over the reference's own assets (obj/ufo_fix.obj, cubemaps/blue_sunset)",
+            "config": {"workload": "BASELINE configs[1]: main.rs world (ufo_fix.obj rope kd-tree, 1705 tris, + 2 spheres), "
+                                   "blue_sunset cubemap, %dx%d, %d spp%s, max_bounce 2, reference ray semantics (prune_zero_mix=%d)"
+                                   % (W, H, spp, " (16 per GPU)" if world > 1 and args.scaling == "weak" else "", args.prune),
+                       "rays_per_step": rays_step, "samples_per_step": paths_step,
+                       "msamples_per_s": paths_step * args.steps / dt / 1e6,
+                       "parallelism": "tiles%d" % world, "traversal_overflow": overflow},
+        }
+        cpu_c = prim_c = None
+        if world == 1 and not args.no_cpu_baseline:
+            nthreads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+            line["cpu_baseline"], cpu_c, prim_c, n_prim = cpu_leg(nthreads)
+        if world == 1:
+            # Dominant kernel = k_wave_primary (one launch per wavefront batch).  Its roofline is priced as
+            # DESIGN.md "Measurement" states: the scene of this config (~0.4 MB of nodes/triangles) is
+            # cache-resident, so the bytes that MUST cross HBM per primary ray are its outputs only:
+            #   finished path: 24 B sample colour (+3 B cubemap texel when it ends in the sky)
+            #   continuing path: 56 B shading record + 52 B queue entry
+            # `achieved` = those bytes x rays per launch / measured launch time (hipEvents on the launch stream).
+            # The kernel is f64-VALU/latency bound; that ceiling is reported beside it as valu_f64.
+            launch_ms = prim_ms / max(prim_n, 1)
+            rays_per_launch = stats["primary_rays"] / max(prim_n, 1)
+            lv = stats["level_rays"]
+            cont = lv[1] / max(lv[0], 1)
+            hbm_bytes_ray = (1.0 - cont) * 27.0 + cont * 108.0
+            ach = hbm_bytes_ray * rays_per_launch / (launch_ms * 1e-3) / 1e9
+            roof = {"kernel": "k_wave_primary", "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                    "achieved": ach, "frac": ach / PEAK_HBM_GBS, "traffic": None,
+                    "avg_launch_ms": launch_ms, "launches_per_step": prim_n, "rays_per_launch": rays_per_launch,
+                    "hbm_bytes_per_ray": hbm_bytes_ray, "continuing_fraction": cont,
+                    "other_kernels": {"k_wave_bounce_ms_per_step": bnc_ms, "k_wave_bounce_launches": bnc_n,
+                                      "k_wave_primary_ms_per_step": prim_ms, "gpu_ms_per_step": stats["gpu_ms"],
+                                      "level_rays": lv}}
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tf):       # PMC FETCH_SIZE/WRITE_SIZE per launch, collected by tools/collect_pmc.sh
+                try:
+                    t = json.load(open(tf)).get("k_wave_primary")
+                    if t:
+                        roof["traffic"] = t["hbm_bytes_per_launch"]
+                        roof["traffic_source"] = t.get("source")
+                except (ValueError, KeyError):
+                    pass
+            if prim_c:
+                n = float(n_prim)
+                per = {k: prim_c[k] / n for k in ("node_steps", "leaf_visits", "tri_tests", "sphere_tests", "box_tests")}
+                onchip = per["node_steps"] * S_NODE + per["leaf_visits"] * S_LEAF + per["tri_tests"] * S_TRI
+                flops_ray = (per["tri_tests"] * F_TRI + per["box_tests"] * F_BOX + per["node_steps"] * F_NODE
+                             + per["sphere_tests"] * F_SPHERE + F_SHADE)
+                tf64 = flops_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12
+                roof["valu_f64"] = {"achieved": tf64, "peak": PEAK_F64_TFLOPS, "frac": tf64 / PEAK_F64_TFLOPS,
+                                    "unit": "TFLOP/s", "flops_per_ray": flops_ray, "per_primary_ray": per,
+                                    "cache_served_bytes_per_ray": onchip,
+                                    "cache_served_GBs": onchip * rays_per_launch / (launch_ms * 1e-3) / 1e9}
+            line["roofline"] = roof
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,9 +84,13 @@ typedef struct rrt_stats {
     uint64_t paths;            /* pixel samples                                                       */
     uint64_t traversal_overflow; /* rays that exceeded the leaf-visit safety bound (expected 0)       */
     double gpu_ms;             /* hipEvent span of the last render's kernels                          */
-    double trace_kernel_ms;    /* summed duration of the trace+shade kernels only                     */
-    uint32_t trace_kernel_launches;
+    double primary_kernel_ms;  /* summed hipEvent duration of the primary-ray kernel launches         */
+    double bounce_kernel_ms;   /* summed hipEvent duration of the bounce-queue kernel launches        */
+    uint32_t primary_kernel_launches;
+    uint32_t bounce_kernel_launches;
     uint32_t n_batches;
+    uint32_t reserved;
+    uint64_t level_rays[4];    /* rays cast at bounce level 0,1,2,3 (level 0 = primary)               */
 } rrt_stats;
 
 #define RRT_TILE_W 32

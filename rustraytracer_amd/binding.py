@@ -29,8 +29,10 @@ class Settings(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_traced", C.c_uint64), ("primary_rays", C.c_uint64), ("paths", C.c_uint64),
                 ("traversal_overflow", C.c_uint64), ("gpu_ms", C.c_double),
-                ("trace_kernel_ms", C.c_double), ("trace_kernel_launches", C.c_uint32),
-                ("n_batches", C.c_uint32)]
+                ("primary_kernel_ms", C.c_double), ("bounce_kernel_ms", C.c_double),
+                ("primary_kernel_launches", C.c_uint32), ("bounce_kernel_launches", C.c_uint32),
+                ("n_batches", C.c_uint32), ("reserved", C.c_uint32),
+                ("level_rays", C.c_uint64 * 4)]
 
 
 # every symbol include/rrt.h and include/rrt_host.h declare

@@ -260,7 +260,7 @@ int ensure_work(rrt_scene* s, const FramePlan& pl, rrt::DWork* wk) {
     HIP_TRY(s->w_recR.ensure(P * 8 * pl.levels));
     HIP_TRY(s->w_samp.ensure(P * 3 * 8));
     HIP_TRY(s->w_accum.ensure((size_t)pl.fr.npx_local * 3 * 8));
-    HIP_TRY(s->w_stats.ensure(4 * 8));
+    HIP_TRY(s->w_stats.ensure(8 * 8));
     wk->q_count = s->w_qcount.as<uint32_t>();
     wk->recA = s->w_recA.as<double>();
     wk->recP = s->w_recP.as<double>();
@@ -303,7 +303,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     }
     s->timed_used = 0;
     HIP_TRY(hipEventRecord(s->ev_begin, stream));
-    HIP_TRY(hipMemsetAsync(wk.stats, 0, 4 * 8, stream));
+    HIP_TRY(hipMemsetAsync(wk.stats, 0, 8 * 8, stream));
     rrt::DFrame fr = pl.fr;
     for (uint32_t b = 0; b < pl.n_batches; ++b) {
         fr.s0 = b * pl.batch_spp;
@@ -577,18 +577,24 @@ int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
     s->stats.gpu_ms = ms;
-    double trace = 0.0;
+    double prim = 0.0, bnc = 0.0;
+    uint32_t nprim = 0, nbnc = 0;
     for (size_t i = 0; i < s->timed_used; ++i) {
         float k = 0.f;
         HIP_TRY(hipEventElapsedTime(&k, s->timed[i].a, s->timed[i].b));
-        trace += k;
+        if (s->timed[i].primary) { prim += k; ++nprim; }
+        else { bnc += k; ++nbnc; }
     }
-    s->stats.trace_kernel_ms = trace;
-    s->stats.trace_kernel_launches = (uint32_t)s->timed_used;
-    unsigned long long dev[4] = {0, 0, 0, 0};
+    s->stats.primary_kernel_ms = prim;
+    s->stats.bounce_kernel_ms = bnc;
+    s->stats.primary_kernel_launches = nprim;
+    s->stats.bounce_kernel_launches = nbnc;
+    unsigned long long dev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(dev, s->w_stats.p, sizeof(dev), hipMemcpyDeviceToHost));
     s->stats.rays_traced = s->stats.primary_rays + dev[0];
     s->stats.traversal_overflow = dev[1];
+    s->stats.level_rays[0] = s->stats.primary_rays;
+    for (int l = 1; l < 4; ++l) s->stats.level_rays[l] = dev[4 + l];
     *out = s->stats;
     return RRT_OK;
 }

@@ -467,7 +467,10 @@ __global__ __launch_bounds__(256) void k_wave_bounce(DScene sc, DWork wk, DFrame
         }
         process_ray<false>(sc, wk, fr, active, path, o, d, bounce, nullptr, nullptr, 0u, false);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wk.stats[0], (unsigned long long)count);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&wk.stats[0], (unsigned long long)count);
+        if (bounce < 4u) atomicAdd(&wk.stats[4 + bounce], (unsigned long long)count);
+    }
 }
 
 // accum[lp] (+)= sum over this batch's samples, in sample order.

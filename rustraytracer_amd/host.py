@@ -175,7 +175,9 @@ class World:
     def stats(self):
         st = B.Stats()
         B.check(B.lib.rrt_get_stats(self.h, C.byref(st)))
-        return {k: getattr(st, k) for k, _ in B.Stats._fields_}
+        d = {k: getattr(st, k) for k, _ in B.Stats._fields_}
+        d["level_rays"] = [int(x) for x in st.level_rays]
+        return d
 
 
 def tile_slots(width, height, world):
