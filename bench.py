@@ -108,11 +108,10 @@ def main():
     spp = SPP * world if args.scaling == "weak" else SPP
     st = Hst.make_settings(W, H, spp=spp, max_bounce=2, seed=0, prune_zero_mix=args.prune,
                            tile_rank=rank, tile_world=world)
+    from rustraytracer_amd import distributed as D
     frame = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
     if world > 1:
-        slots = Hst.tile_slots(W, H, world)
-        local = torch.empty((slots, 8, 32, 3), dtype=torch.uint8, device=dev)
-        gathered = torch.empty((world, slots, 8, 32, 3), dtype=torch.uint8, device=dev)
+        local, gathered = D.alloc_tile_buffers(W, H, world, dev)
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
@@ -120,7 +119,7 @@ def main():
             scene.render_device(st, frame.data_ptr(), stream=stream)
         else:
             scene.render_device(st, local.data_ptr(), stream=stream)
-            dist.all_gather_into_tensor(gathered, local)
+            D.gather_tiles(local, gathered)
             Hst.assemble_tiles(gathered.data_ptr(), W, H, world, frame.data_ptr(), stream=stream)
 
     def sync():
@@ -145,13 +144,9 @@ def main():
     prim_ms, prim_n = stats["primary_kernel_ms"], stats["primary_kernel_launches"]
     bnc_ms, bnc_n = stats["bounce_kernel_ms"], stats["bounce_kernel_launches"]
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    rays = torch.tensor([stats["rays_traced"], stats["paths"], stats["traversal_overflow"]], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-    dt = float(t.item())
-    rays_step, paths_step, overflow = (int(x) for x in rays.tolist())
+    dt = D.max_over_ranks(dt, dev)
+    rays_step, paths_step, overflow = D.sum_over_ranks(
+        [stats["rays_traced"], stats["paths"], stats["traversal_overflow"]], dev)
 
     if rank == 0:
         value = rays_step * args.steps / dt / 1e6

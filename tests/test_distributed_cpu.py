@@ -1,0 +1,81 @@
+"""The N>1 path on CPU: world_size-2 and -3 gloo groups run the same
+tile-ownership / all-gather / de-interleave sequence bench.py runs over RCCL.
+Each rank's compact tile buffer is cut from an oracle-rendered frame (the GPU
+render itself is covered by tests/test_parity_gpu.py::test_tile_sharding_*)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, frame, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rustraytracer_amd import distributed as D, tiles
+        h, w = frame.shape[:2]
+        local, gathered = D.alloc_tile_buffers(w, h, world, "cpu")
+        local.copy_(torch.from_numpy(tiles.extract_rank_tiles(frame, rank, world)))
+        D.gather_tiles(local, gathered)
+        out = tiles.assemble_numpy(gathered.numpy(), w, h, world)
+        tmax = D.max_over_ranks(float(rank + 1), "cpu")
+        tot = D.sum_over_ranks([rank + 1, 10], "cpu")
+        q.put((rank, bool(np.array_equal(out, frame)), tmax, tot))
+    except Exception as e:      # surface the failure instead of leaving the parent waiting on the queue
+        q.put((rank, False, repr(e), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size", [(2, (100, 75)), (3, (33, 9)), (2, (64, 16))])
+def test_tile_gather_over_gloo(O, scenes, world, size):
+    w, h = size
+    frame = scenes.cfg1_scene(O.OracleScene(), O).render(w, h, n_threads=2, want=("rgb",))["rgb"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, frame, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    for _, same, tmax, tot in res:
+        assert same
+        assert tmax == float(world)
+        assert tot == [world * (world + 1) // 2, 10 * world]
+
+
+def test_tile_ownership_is_a_partition():
+    from rustraytracer_amd import tiles
+    for (w, h, world) in ((1920, 1080, 8), (3840, 2160, 8), (33, 9, 2), (500, 270, 3)):
+        tx, ty = tiles.tile_grid(w, h)
+        slots = tiles.tile_slots(w, h, world)
+        seen = set()
+        for t in range(tx * ty):
+            r, s = tiles.owner_of_tile(t, world)
+            assert 0 <= r < world and 0 <= s < slots
+            seen.add((r, s))
+        assert len(seen) == tx * ty
+        # balanced within one tile
+        per = [sum(1 for (r, _) in seen if r == k) for k in range(world)]
+        assert max(per) - min(per) <= 1
