@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--prune", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--batch-spp", type=int, default=0, help="samples per pixel per wavefront batch (0 = from the work budget)")
+    ap.add_argument("--budget-gib", type=float, default=0.0, help="work-buffer budget in GiB (0 = library default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,10 +106,12 @@ def main():
 
     from rustraytracer_amd import host as Hst, scenes
     scene = scenes.cfg2_scene(Hst.World(device=local_rank), Hst.loaders)
+    if args.budget_gib > 0:
+        scene.set_work_budget(int(args.budget_gib * (1 << 30)))
     scene.commit()                                   # scene resident in HBM before timing
     spp = SPP * world if args.scaling == "weak" else SPP
     st = Hst.make_settings(W, H, spp=spp, max_bounce=2, seed=0, prune_zero_mix=args.prune,
-                           tile_rank=rank, tile_world=world)
+                           tile_rank=rank, tile_world=world, batch_spp=args.batch_spp)
     from rustraytracer_amd import distributed as D
     frame = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
     if world > 1:

@@ -91,6 +91,7 @@ typedef struct rrt_stats {
     uint32_t n_batches;
     uint32_t reserved;
     uint64_t level_rays[4];    /* rays cast at bounce level 0,1,2,3 (level 0 = primary)               */
+    uint64_t cull_violations;  /* cull mode 2 only: entries the cull skipped but the exact test accepts (must be 0) */
 } rrt_stats;
 
 #define RRT_TILE_W 32
@@ -146,8 +147,14 @@ int rrt_set_directional_light(rrt_scene* s, const double direction[3], const dou
 int rrt_set_ambient(rrt_scene* s, double ambient);             /* World.ambient, tracer.rs:73 */
 
 /* Upper bound in bytes for per-render wavefront work buffers (queues, path
- * records, sample buffer).  Default 4 GiB. */
+ * records, sample buffer).  Default 16 GiB. */
 int rrt_set_work_budget(rrt_scene* s, uint64_t bytes);
+
+/* Conservative triangle cull inside the kd leaves (no reference counterpart; results are
+ * bit-identical by construction, see rrt_kernels.hip): 0 = off (every triangle of a visited leaf
+ * gets the exact f64 test, as kdtree.rs:203-212), 1 = on (default), 2 = verify (run both, count
+ * disagreements in rrt_stats.cull_violations). */
+int rrt_set_cull_mode(rrt_scene* s, int mode);
 
 /* Uploads the scene to the device (idempotent; render calls it if needed). */
 int rrt_scene_commit(rrt_scene* s);

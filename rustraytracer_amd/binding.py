@@ -32,7 +32,7 @@ class Stats(C.Structure):
                 ("primary_kernel_ms", C.c_double), ("bounce_kernel_ms", C.c_double),
                 ("primary_kernel_launches", C.c_uint32), ("bounce_kernel_launches", C.c_uint32),
                 ("n_batches", C.c_uint32), ("reserved", C.c_uint32),
-                ("level_rays", C.c_uint64 * 4)]
+                ("level_rays", C.c_uint64 * 4), ("cull_violations", C.c_uint64)]
 
 
 # every symbol include/rrt.h and include/rrt_host.h declare
@@ -40,7 +40,8 @@ EXPORTS = [
     "rrt_last_error", "rrt_version", "rrt_set_device", "rrt_device_image_support",
     "rrt_default_camera", "rrt_default_settings", "rrt_scene_create", "rrt_scene_destroy",
     "rrt_add_material", "rrt_add_sphere", "rrt_add_mesh", "rrt_set_sky_face",
-    "rrt_set_directional_light", "rrt_set_ambient", "rrt_set_work_budget", "rrt_scene_commit",
+    "rrt_set_directional_light", "rrt_set_ambient", "rrt_set_work_budget", "rrt_set_cull_mode",
+    "rrt_scene_commit",
     "rrt_render", "rrt_render_device", "rrt_tile_slots", "rrt_assemble_tiles",
     "rrt_trace_rays", "rrt_cast_rays", "rrt_get_stats", "rrt_mesh_tree_sizes",
     "rrt_mesh_tree_export", "rrt_selftest_math", "rrt_philox4x32_10",
@@ -83,6 +84,7 @@ def _load():
     L.rrt_set_directional_light.argtypes = [vp, dp, dp, C.c_double]
     L.rrt_set_ambient.argtypes = [vp, C.c_double]
     L.rrt_set_work_budget.argtypes = [vp, u64]
+    L.rrt_set_cull_mode.argtypes = [vp, i32]
     L.rrt_scene_commit.argtypes = [vp]
     L.rrt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp]
     L.rrt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp, vp]

@@ -62,7 +62,7 @@ struct HostMesh {
     rrt::KdTreeFlat tree;
     int material = 0;
     // device copies
-    DevBuf d_nodes, d_refs, d_tris, d_normals;
+    DevBuf d_nodes, d_boxes, d_leaves, d_refs, d_tris, d_normals, d_cull;
 };
 
 struct SkyFace {
@@ -92,7 +92,8 @@ struct rrt_scene {
     bool has_light = false;
     double light_dir[3] = {0, 0, 0}, light_color[3] = {0, 0, 0}, light_intensity = 0.0;
     double ambient = 0.15;  // tracer.rs:73
-    uint64_t work_budget = 4ull << 30;
+    uint64_t work_budget = 16ull << 30;
+    int cull_mode = 1;
 
     bool dirty = true;
     DevBuf d_ents, d_spheres, d_meshes, d_mats;
@@ -130,25 +131,78 @@ int commit(rrt_scene* s) {
     for (size_t i = 0; i < s->meshes.size(); ++i) {
         HostMesh& m = *s->meshes[i];
         const rrt::KdTreeFlat& T = m.tree;
-        std::vector<rrt::DNode> nodes((size_t)T.n_nodes());
-        for (size_t k = 0; k < nodes.size(); ++k) {
-            rrt::DNode& n = nodes[k];
+        const size_t nn = (size_t)T.n_nodes();
+        std::vector<rrt::DNodeI> nodes(nn);
+        std::vector<rrt::DBox> boxes(nn);
+        std::vector<rrt::DLeaf> leaves;
+        for (size_t k = 0; k < nn; ++k) {
             for (int a = 0; a < 3; ++a) {
-                n.mn[a] = T.boxes[6 * k + a];
-                n.mx[a] = T.boxes[6 * k + 3 + a];
+                boxes[k].mn[a] = T.boxes[6 * k + a];
+                boxes[k].mx[a] = T.boxes[6 * k + 3 + a];
             }
-            n.split = T.split[k];
-            n.axis = T.axis[k];
-            n.c0 = T.child[2 * k];
-            n.c1 = T.child[2 * k + 1];
-            for (int r = 0; r < 6; ++r) n.rope[r] = T.ropes[6 * k + r];
-            n.pad = 0;
+            nodes[k].split = T.split[k];
+            nodes[k].axis = T.axis[k];
+            if (T.axis[k] >= 0) {
+                // pre-order: the left child directly follows its parent
+                if (T.child[2 * k] != (int32_t)k + 1) return fail(RRT_E_STATE, "kd-tree is not in pre-order");
+                nodes[k].right = T.child[2 * k + 1];
+            } else {
+                rrt::DLeaf L{};
+                for (int a = 0; a < 3; ++a) {
+                    L.mn[a] = boxes[k].mn[a];
+                    L.mx[a] = boxes[k].mx[a];
+                }
+                for (int r = 0; r < 6; ++r) L.rope[r] = T.ropes[6 * k + r];
+                L.first = T.child[2 * k];
+                L.count = T.child[2 * k + 1];
+                nodes[k].right = (int32_t)leaves.size();
+                leaves.push_back(L);
+            }
         }
-        HIP_TRY(m.d_nodes.upload(nodes.data(), nodes.size() * sizeof(rrt::DNode)));
+        HIP_TRY(m.d_nodes.upload(nodes.data(), nodes.size() * sizeof(rrt::DNodeI)));
+        HIP_TRY(m.d_boxes.upload(boxes.data(), boxes.size() * sizeof(rrt::DBox)));
+        HIP_TRY(m.d_leaves.upload(leaves.data(), leaves.size() * sizeof(rrt::DLeaf)));
         HIP_TRY(m.d_refs.upload(T.leaf_refs.data(), T.leaf_refs.size() * sizeof(int32_t)));
-        HIP_TRY(m.d_tris.upload(m.tris.data(), m.tris.size() * sizeof(rrt::DTri)));
+        std::vector<rrt::DTri> stream(T.leaf_refs.size());
+        for (size_t j = 0; j < stream.size(); ++j) stream[j] = m.tris[(size_t)T.leaf_refs[j]];
+        HIP_TRY(m.d_tris.upload(stream.data(), stream.size() * sizeof(rrt::DTri)));
+        // outward-rounded f32 boxes of the stream entries + the cull constants
+        std::vector<rrt::DBox32> cull(stream.size());
+        double edge_max = 0.0;
+        for (size_t j = 0; j < stream.size(); ++j) {
+            const rrt::DTri& t = stream[j];
+            double l1 = 0.0, l2 = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                const double p0 = t.v0[a], p1 = t.v0[a] + t.e1[a], p2 = t.v0[a] + t.e2[a];
+                const double lo = std::fmin(p0, std::fmin(p1, p2)), hi = std::fmax(p0, std::fmax(p1, p2));
+                float flo = (float)lo, fhi = (float)hi;
+                if ((double)flo > lo) flo = std::nextafterf(flo, -INFINITY);
+                if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
+                cull[j].mn[a] = std::nextafterf(flo, -INFINITY);   // one more ulp for the p0+e rounding
+                cull[j].mx[a] = std::nextafterf(fhi, INFINITY);
+                l1 += t.e1[a] * t.e1[a];
+                l2 += t.e2[a] * t.e2[a];
+            }
+            edge_max = std::fmax(edge_max, std::sqrt(std::fmax(l1, l2)));
+        }
+        HIP_TRY(m.d_cull.upload(cull.data(), cull.size() * sizeof(rrt::DBox32)));
+        dm[i].cull = m.d_cull.as<rrt::DBox32>();
+        dm[i].edge_max = edge_max * (1.0 + 1e-9);
+        {
+            double r2 = 0.0, am = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                const double lo = T.boxes[a], hi = T.boxes[3 + a];
+                dm[i].center[a] = 0.5 * (lo + hi);
+                r2 += 0.25 * (hi - lo) * (hi - lo);
+                am = std::fmax(am, std::fmax(std::fabs(lo), std::fabs(hi)));
+            }
+            dm[i].radius = std::sqrt(r2) * (1.0 + 1e-9);
+            dm[i].abs_max = am;
+        }
         HIP_TRY(m.d_normals.upload(m.normals.data(), m.normals.size() * sizeof(double)));
-        dm[i].nodes = m.d_nodes.as<rrt::DNode>();
+        dm[i].nodes = m.d_nodes.as<rrt::DNodeI>();
+        dm[i].boxes = m.d_boxes.as<rrt::DBox>();
+        dm[i].leaves = m.d_leaves.as<rrt::DLeaf>();
         dm[i].leaf_refs = m.d_refs.as<int32_t>();
         dm[i].tris = m.d_tris.as<rrt::DTri>();
         dm[i].normals = m.d_normals.as<double>();
@@ -172,6 +226,16 @@ int commit(rrt_scene* s) {
     }
     d.light_intensity = s->light_intensity;
     d.ambient = s->ambient;
+    d.cull_mode = s->cull_mode;
+    // the first mesh whose descent array fits is staged in LDS by the trace kernels
+    d.lds_mesh = -1;
+    d.lds_nodes = 0;
+    for (size_t i = 0; i < s->meshes.size(); ++i)
+        if (s->meshes[i]->tree.n_nodes() <= rrt::kMaxLdsNodes) {
+            d.lds_mesh = (int32_t)i;
+            d.lds_nodes = s->meshes[i]->tree.n_nodes();
+            break;
+        }
     for (int f = 0; f < 6; ++f) {
         HIP_TRY(s->sky[f].d.upload(s->sky[f].rgb.data(), s->sky[f].rgb.size()));
         d.sky[f] = s->sky[f].d.as<uint8_t>();
@@ -474,6 +538,13 @@ int rrt_set_work_budget(rrt_scene* s, uint64_t bytes) {
     return RRT_OK;
 }
 
+int rrt_set_cull_mode(rrt_scene* s, int mode) {
+    if (!s || mode < 0 || mode > 2) return fail(RRT_E_INVALID, "cull mode must be 0, 1 or 2");
+    s->cull_mode = mode;
+    s->dirty = true;
+    return RRT_OK;
+}
+
 int rrt_scene_commit(rrt_scene* s) {
     if (!s) return fail(RRT_E_INVALID, "null scene");
     return commit(s);
@@ -593,6 +664,7 @@ int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) {
     HIP_TRY(hipMemcpy(dev, s->w_stats.p, sizeof(dev), hipMemcpyDeviceToHost));
     s->stats.rays_traced = s->stats.primary_rays + dev[0];
     s->stats.traversal_overflow = dev[1];
+    s->stats.cull_violations = dev[2];
     s->stats.level_rays[0] = s->stats.primary_rays;
     for (int l = 1; l < 4; ++l) s->stats.level_rays[l] = dev[4 + l];
     *out = s->stats;

@@ -13,21 +13,33 @@ namespace rrt {
 constexpr uint32_t kMaxLeafVisits = 1u << 16;
 constexpr int kMaxLevels = 18;  // max_bounce + 2 casts per path, max_bounce <= 16
 
-// One kd node, 96 bytes.  Interior: axis 0..2, split, c0/c1 = children.
-// Leaf: axis -1, c0/c1 = first/count into leaf_refs, rope[6].  The box is kept
-// for every node because find_point tests the rope target's box, and rope
-// targets may be interior nodes (kdtree.rs:23-24, 139-161).
-struct DNode {
+// kd-tree in three arrays (pre-order node numbering, left child = index + 1):
+//   DNodeI[node]  16 B  what find_point's descent reads (kdtree.rs:27-31): split, axis, and the
+//                       right child (interior) or the leaf number (axis < 0).  Small enough
+//                       (ufo: 27 KB) to be staged whole in LDS by the trace kernels.
+//   DBox[node]    48 B  every node's box: find_point tests the box of the node it starts from,
+//                       and rope targets may be interior nodes (kdtree.rs:23-24, 139-161).
+//   DLeaf[leaf]   80 B  box again (exit test + get_plane), ropes, range in the triangle stream.
+struct DNodeI {
+    double split;
+    int32_t axis;    // 0..2, or -1 for a leaf
+    int32_t right;   // interior: right child node; leaf: index into DLeaf[]
+};
+static_assert(sizeof(DNodeI) == 16, "DNodeI layout");
+
+struct DBox {
     double mn[3];
     double mx[3];
-    double split;
-    int32_t axis;
-    int32_t c0;
-    int32_t c1;
-    int32_t rope[6];
-    int32_t pad;
 };
-static_assert(sizeof(DNode) == 96, "DNode layout");
+
+struct DLeaf {
+    double mn[3];
+    double mx[3];
+    int32_t rope[6];   // node index or -1; 0..2 = -x,-y,-z faces, 3..5 = +x,+y,+z
+    int32_t first;     // first entry in the triangle stream
+    int32_t count;
+};
+static_assert(sizeof(DLeaf) == 80, "DLeaf layout");
 
 // Per triangle: v0, e1 = v1 - v0, e2 = v2 - v0 (the two subtractions of
 // triangle.rs:30-31 hoisted to scene build; same IEEE results), 72 bytes.
@@ -37,13 +49,28 @@ struct DTri {
     double e2[3];
 };
 
+// f32 bounding box of one triangle-stream entry, rounded outward (cull test only).
+struct DBox32 {
+    float mn[3];
+    float mx[3];
+};
+
 struct DMesh {
-    const DNode* nodes;
-    const int32_t* leaf_refs;
-    const DTri* tris;
-    const double* normals;  // 3 per triangle
+    const DNodeI* nodes;
+    const DBox* boxes;
+    const DLeaf* leaves;
+    const int32_t* leaf_refs;   // triangle id of stream entry j
+    const DTri* tris;           // leaf-ordered stream: entry j = the triangle leaf_refs[j] (duplicated per
+                                // leaf, so a leaf's triangles are contiguous and the next one can be prefetched)
+    const double* normals;  // 3 per triangle (indexed by triangle id)
+    const DBox32* cull;     // per stream entry, see "conservative cull" in rrt_kernels.hip
     int32_t material;
     int32_t n_nodes;
+    // constants of the conservative cull (host-computed, f64)
+    double center[3];       // root box centre
+    double radius;          // root box half diagonal
+    double edge_max;        // S = max |e1|,|e2| over the mesh
+    double abs_max;         // largest |coordinate| of the root box
 };
 
 struct DSphere {
@@ -80,7 +107,13 @@ struct DScene {
     const uint8_t* sky[6];   // RGB8 rows
     uint32_t sky_w[6];
     uint32_t sky_h[6];
+    int32_t lds_mesh;        // mesh whose DNodeI array the trace kernels stage in LDS, or -1
+    int32_t lds_nodes;       // its node count (LDS bytes = 16 * lds_nodes)
+    int32_t cull_mode;       // 0 = off, 1 = on, 2 = verify (run both, count cull-vs-exact disagreements)
+    int32_t pad0;
 };
+
+constexpr int32_t kMaxLdsNodes = 3072;   // 48 KB of LDS per 256-thread block at most
 
 // Ray queue, SoA.  cap entries each.
 struct DQueue {

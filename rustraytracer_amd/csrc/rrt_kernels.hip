@@ -152,9 +152,21 @@ RRT_DEV V3 box_exit(V3 mn, V3 mx, V3 o, V3 d, V3 inv) {
 // ---------------------------------------------------------------------------
 // Triangle::collide (triangle.rs:25-58) on the pre-subtracted edges.
 // ---------------------------------------------------------------------------
-RRT_DEV bool tri_collide(const DTri* __restrict__ T, V3 o, V3 d, double* tout) {
+// Scene pointers are read out of structs in memory, so the compiler only knows them as generic
+// ("flat") pointers; these casts give it global_load instead of flat_load on the hot arrays.
+#define RRT_GLOBAL __attribute__((address_space(1)))
+template <class T>
+RRT_DEV const RRT_GLOBAL T* as_global(const T* p) { return (const RRT_GLOBAL T*)p; }
+RRT_DEV V3 ld3g(const RRT_GLOBAL double* p) { return V3{p[0], p[1], p[2]}; }
+
+struct TriData {
+    V3 v0, e1, e2;
+};
+RRT_DEV TriData ld_tri(const RRT_GLOBAL DTri* T) { return TriData{ld3g(T->v0), ld3g(T->e1), ld3g(T->e2)}; }
+
+RRT_DEV bool tri_collide(const TriData& T, V3 o, V3 d, double* tout) {
     const double EPS = 0.0000001;
-    const V3 e1 = ld3(T->e1), e2 = ld3(T->e2), v0 = ld3(T->v0);
+    const V3 e1 = T.e1, e2 = T.e2, v0 = T.v0;
     const V3 h = cross(d, e2);
     const double a = dot(e1, h);
     if (a > -EPS && a < EPS) return false;
@@ -182,18 +194,27 @@ struct Hit {
     V3 normal;
 };
 
-// KDTree::find_point (kdtree.rs:23-33).  Returns leaf index or -1.
-RRT_DEV int32_t find_point(const DNode* __restrict__ nodes, int32_t at, V3 p) {
-    const DNode* n = nodes + at;
-    if (!box_contains(ld3(n->mn), ld3(n->mx), p)) return -1;
-    int32_t axis = n->axis;
-    while (axis >= 0) {
-        const double pv = comp(p, axis);
-        at = (pv >= n->split) ? n->c1 : n->c0;
-        n = nodes + at;
-        axis = n->axis;
+// KDTree::find_point (kdtree.rs:23-33) starting at node `at`.  Returns the leaf number or -1.
+// `lnodes` != nullptr: this mesh's descent array is staged in LDS (wave-uniform choice).
+RRT_DEV int32_t find_point(const DMesh& M, const DNodeI* lnodes, int32_t at, V3 p) {
+    const RRT_GLOBAL DBox* bx = as_global(M.boxes) + at;
+    if (!box_contains(ld3g(bx->mn), ld3g(bx->mx), p)) return -1;
+    if (lnodes) {
+        DNodeI n = lnodes[at];
+        while (n.axis >= 0) {
+            at = (comp(p, n.axis) >= n.split) ? n.right : at + 1;   // pre-order: left child = at + 1
+            n = lnodes[at];
+        }
+        return n.right;
     }
-    return at;
+    const RRT_GLOBAL DNodeI* gn = as_global(M.nodes);
+    double split = gn[at].split;
+    int32_t axis = gn[at].axis, right = gn[at].right;
+    while (axis >= 0) {
+        at = (comp(p, axis) >= split) ? right : at + 1;
+        split = gn[at].split; axis = gn[at].axis; right = gn[at].right;
+    }
+    return right;
 }
 
 // get_plane (kdtree.rs:237-244)
@@ -206,89 +227,225 @@ RRT_DEV int get_plane(V3 p, V3 mn, V3 mx) {
     return 5;
 }
 
-// KDTree::collide (kdtree.rs:192-235)
-RRT_DEV void mesh_collide(const DMesh* __restrict__ M, V3 o, V3 d, V3 inv, Hit* out, unsigned long long* stats) {
-    out->hit = false;
-    const DNode* __restrict__ nodes = M->nodes;
+// ---------------------------------------------------------------------------
+// Conservative cull.  Most triangles of a leaf are nowhere near the ray (ufo: ~94 % of the
+// tests), and the exact f64 Moller-Trumbore test costs ~90 f64 instructions.  A triangle is
+// skipped when the ray provably cannot be ACCEPTED by triangle.rs:25-58 evaluated in f64, so
+// the result is unchanged bit for bit.  Argument (u = 2^-53, S = longest edge of the mesh,
+// R >= |o - v0|): an accepted test has |a| >= 1e-7, hence its computed barycentrics and t differ
+// from the exact ones of the ray/plane intersection by at most
+//     du, dv <= 9u*R*S*|d|/1e-7 + 9u*S^2*|d|/1e-7  ~= 1e-8 * S*|d|*(R+S),    dt <= 1e-8 * S^2 * R
+// so the exact line passes within 3*S*du of the triangle, at a parameter >= -dt.  The cull tests
+// the ray against the triangle's box inflated by pad >= 8x that bound (plus the f32 conversion
+// error of the origin), in f32 with outward-rounded boxes and a relative slack on the interval
+// comparison; every rounding errs towards "keep".  cull_mode 2 runs both tests and counts
+// disagreements (expected and tested: 0).
+// ---------------------------------------------------------------------------
+struct F3 {
+    float x, y, z;
+};
+struct CullRay {
+    F3 om, op, inv;   // origin + pad, origin - pad, 1/d
+    float tmin;       // -(bound on dt)
+};
+
+RRT_DEV CullRay make_cull_ray(const DMesh& M, V3 o, V3 d) {
+    const double dl = fabs(d.x) + fabs(d.y) + fabs(d.z);                       // >= |d|
+    const double R = fabs(o.x - M.center[0]) + fabs(o.y - M.center[1]) + fabs(o.z - M.center[2]) + M.radius;
+    const double S = M.edge_max;
+    const double omax = fmax(fabs(o.x), fmax(fabs(o.y), fabs(o.z)));
+    const double pad = 2.5e-7 * S * S * dl * (R + S) + 0x1p-20 * (omax + M.abs_max);
+    const float padf = (float)(pad * 1.000001) + 1e-30f;
+    CullRay c;
+    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
+    c.om = F3{ox + padf, oy + padf, oz + padf};
+    c.op = F3{ox - padf, oy - padf, oz - padf};
+    c.inv = F3{1.0f / (float)d.x, 1.0f / (float)d.y, 1.0f / (float)d.z};
+    c.tmin = -((float)(8e-8 * S * S * (R + S) * 1.000001) + 1e-30f);
+    return c;
+}
+
+struct Box32 {
+    float a0, a1, a2, b0, b1, b2;
+};
+RRT_DEV Box32 ld_box32(const RRT_GLOBAL DBox32* p) { return Box32{p->mn[0], p->mn[1], p->mn[2], p->mx[0], p->mx[1], p->mx[2]}; }
+
+// true = keep (the exact test must run).  NaN-safe: any NaN comparison falls to "keep".
+RRT_DEV bool cull_keep(const Box32& b, const CullRay& c) {
+    const float t0x = (b.a0 - c.om.x) * c.inv.x, t1x = (b.b0 - c.op.x) * c.inv.x;
+    const float t0y = (b.a1 - c.om.y) * c.inv.y, t1y = (b.b1 - c.op.y) * c.inv.y;
+    const float t0z = (b.a2 - c.om.z) * c.inv.z, t1z = (b.b2 - c.op.z) * c.inv.z;
+    const float tlo = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    const float thi = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    const float hi = thi + 0x1p-18f * (fabsf(tlo) + fabsf(thi));
+    return !(hi < tlo) && !(hi < c.tmin);
+}
+
+// Closest accepted triangle of a leaf.  Only what the comparisons need is kept live in the
+// traversal loop (register pressure decides how many waves hide the memory latency); position
+// and normal are rebuilt afterwards from t with the same expressions.
+struct LeafBest {
+    double dist, t;
+    int32_t entry;   // index in the triangle stream, -1 = none
+};
+
+// One Triangle::collide + the closest-in-leaf bookkeeping of kdtree.rs:203-212.
+RRT_DEV void leaf_test(const TriData& T, int32_t entry, V3 o, V3 d, LeafBest* b) {
+    double t;
+    if (tri_collide(T, o, d, &t)) {
+        const V3 pos = o + d * t;                 // triangle.rs:53
+        const double dist = mag2(pos - o);        // kdtree.rs:206
+        if (dist < b->dist) {
+            b->dist = dist; b->t = t; b->entry = entry;
+        }
+    }
+}
+
+template <int CULL>
+RRT_DEV void cull_or_test(const Box32& b, const RRT_GLOBAL DTri* tri, int32_t entry, V3 o, V3 d, const CullRay& cr,
+                          LeafBest* best, unsigned long long* stats) {
+    const bool keep = cull_keep(b, cr);
+    if (keep || CULL == 2) {
+        const TriData T = ld_tri(tri);
+        if (CULL == 2 && !keep) {   // verify mode: the exact test must agree that this entry is not a hit
+            double t;
+            if (tri_collide(T, o, d, &t)) atomicAdd(&stats[2], 1ull);
+        }
+        leaf_test(T, entry, o, d, best);
+    }
+}
+
+// KDTree::collide (kdtree.rs:192-235).  Returns the winning stream entry in out->entry (-1 = miss).
+template <int CULL>
+RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, V3 inv, LeafBest* out,
+                          unsigned long long* stats) {
+    out->entry = -1; out->dist = kF64Max; out->t = 0.0;
     V3 point;
-    if (!box_collide(ld3(nodes[0].mn), ld3(nodes[0].mx), o, d, inv, &point)) return;
+    {
+        const RRT_GLOBAL DBox* rb = as_global(M.boxes);
+        if (!box_collide(ld3g(rb->mn), ld3g(rb->mx), o, d, inv, &point)) return;
+    }
     point = point + d * 0.01;
-    int32_t leaf = find_point(nodes, 0, point);
-    const int32_t* __restrict__ refs = M->leaf_refs;
-    const DTri* __restrict__ tris = M->tris;
+    int32_t leaf = find_point(M, lnodes, 0, point);
+    CullRay cr;
+    if (CULL != 0) cr = make_cull_ray(M, o, d);
+    const RRT_GLOBAL DLeaf* leaves = as_global(M.leaves);
+    const RRT_GLOBAL DTri* stream = as_global(M.tris);
     uint32_t visits = 0;
     while (leaf >= 0) {
         if (++visits > kMaxLeafVisits) {
             atomicAdd(&stats[1], 1ull);
             return;
         }
-        const DNode* n = nodes + leaf;
-        const int32_t first = n->c0, count = n->c1;
-        double best = kF64Max, best_t = 0.0;
-        int32_t best_tri = -1;
-        V3 best_pos = mk(0., 0., 0.);
-        for (int32_t k = 0; k < count; ++k) {
-            const int32_t id = refs[first + k];
-            double t;
-            if (tri_collide(tris + id, o, d, &t)) {
-                const V3 pos = o + d * t;
-                const double dist = mag2(pos - o);
-                if (dist < best) {
-                    best = dist; best_t = t; best_tri = id; best_pos = pos;
-                }
+        const RRT_GLOBAL DLeaf* L = leaves + leaf;
+        const int32_t first = L->first, count = L->count;
+        LeafBest best;
+        best.dist = kF64Max; best.t = 0.0; best.entry = -1;
+        const RRT_GLOBAL DTri* tp = stream + first;
+        const int32_t last = count - 1;
+        if (CULL == 0) {
+            // Software pipeline over the leaf's contiguous triangle stream, unrolled by two so the
+            // prefetched triangle lands in the other register set (no copies): while A is tested B
+            // is in flight and vice versa.  The clamped index re-reads the last one instead of branching.
+            TriData A = ld_tri(tp);
+            for (int32_t k = 0; k < count; k += 2) {
+                const TriData B = ld_tri(tp + (k + 1 < last ? k + 1 : last));
+                leaf_test(A, first + k, o, d, &best);
+                A = ld_tri(tp + (k + 2 < last ? k + 2 : last));
+                if (k + 1 < count) leaf_test(B, first + k + 1, o, d, &best);
+            }
+        } else {
+            // Same pipeline over the 24-byte cull boxes; the 72-byte f64 triangle is fetched only
+            // for the entries that survive the cull.
+            const RRT_GLOBAL DBox32* bp = as_global(M.cull) + first;
+            Box32 A = ld_box32(bp);
+            for (int32_t k = 0; k < count; k += 2) {
+                const Box32 B = ld_box32(bp + (k + 1 < last ? k + 1 : last));
+                cull_or_test<CULL>(A, tp + k, first + k, o, d, cr, &best, stats);
+                A = ld_box32(bp + (k + 2 < last ? k + 2 : last));
+                if (k + 1 < count) cull_or_test<CULL>(B, tp + k + 1, first + k + 1, o, d, cr, &best, stats);
             }
         }
-        if (best_tri >= 0) {
-            out->hit = true; out->tri = best_tri; out->t = best_t; out->pos = best_pos;
-            out->normal = ld3(M->normals + 3 * (size_t)best_tri);
-            out->mat = M->material;
+        if (best.entry >= 0) {
+            *out = best;
             return;
         }
-        const V3 mn = ld3(n->mn), mx = ld3(n->mx);
+        const V3 mn = ld3g(L->mn), mx = ld3g(L->mx);
         point = box_exit(mn, mx, point, d, inv) + d * 0.001;
-        const int32_t nb = n->rope[get_plane(point, mn, mx)];
+        const int32_t nb = L->rope[get_plane(point, mn, mx)];
         if (nb < 0) return;
-        leaf = find_point(nodes, nb, point);
+        leaf = find_point(M, lnodes, nb, point);
     }
 }
 
-// Sphere::collide (sphere.rs:28-47)
-RRT_DEV void sphere_collide(const DSphere* __restrict__ S, V3 o, V3 d, Hit* out) {
-    out->hit = false;
-    const V3 c = ld3(S->c);
-    const V3 l = c - o;
+// Sphere::collide (sphere.rs:28-47): the hit parameter only; position and normal are rebuilt by
+// finish_hit for the entity that wins.
+RRT_DEV bool sphere_collide(const DSphere* __restrict__ S, V3 o, V3 d, double* tout) {
+    const V3 l = ld3(S->c) - o;
     const double tca = dot(l, d);
-    if (tca < 0.0) return;
+    if (tca < 0.0) return false;
     const double d2 = mag2(l) - tca * tca;
     const double r2 = S->r2;
-    if (d2 > r2) return;
+    if (d2 > r2) return false;
     const double thc = sqrt(r2 - d2);
-    const double t = tca - thc;
-    out->hit = true; out->tri = -1; out->t = t; out->mat = S->material;
-    out->pos = o + d * t;
-    out->normal = normalize(out->pos - c);
+    *tout = tca - thc;
+    return true;
 }
 
+struct Closest {
+    double dist, t;
+    int32_t ent;     // entity id, -1 = miss
+    int32_t entry;   // mesh: winning stream entry
+};
+
 // The entity loop of RayTracer::cast (tracer.rs:178-190)
-RRT_DEV int32_t closest_hit(const DScene& sc, V3 o, V3 d, Hit* best, unsigned long long* stats) {
+template <int CULL>
+RRT_DEV void closest_hit(const DScene& sc, const DNodeI* lnodes, V3 o, V3 d, Closest* best,
+                         unsigned long long* stats) {
     const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);   // aabb.rs:74, same for every box test of this ray
-    double min_d = kF64Max;
-    int32_t best_ent = -1;
-    best->hit = false; best->tri = -1; best->t = 0.0; best->mat = -1;
-    best->pos = mk(0., 0., 0.); best->normal = mk(0., 0., 0.);
+    best->dist = kF64Max; best->t = 0.0; best->ent = -1; best->entry = -1;
     for (int32_t e = 0; e < sc.n_ents; ++e) {
         const DEntity ent = sc.ents[e];
-        Hit h;
-        if (ent.kind == 0) sphere_collide(sc.spheres + ent.index, o, d, &h);
-        else mesh_collide(sc.meshes + ent.index, o, d, inv, &h, stats);
-        if (h.hit) {
-            const double dist = mag2(h.pos - o);
-            if (dist < min_d) {
-                min_d = dist; *best = h; best_ent = e;
+        if (ent.kind == 0) {
+            double t;
+            if (sphere_collide(sc.spheres + ent.index, o, d, &t)) {
+                const V3 pos = o + d * t;                  // sphere.rs:39
+                const double dist = mag2(pos - o);         // tracer.rs:184
+                if (dist < best->dist) { best->dist = dist; best->t = t; best->ent = e; best->entry = -1; }
+            }
+        } else {
+            const DMesh M = sc.meshes[ent.index];
+            LeafBest h;
+            mesh_collide<CULL>(M, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, inv, &h, stats);
+            // same |pos - origin|^2 as the leaf-level metric (kdtree.rs:206 == tracer.rs:184)
+            if (h.entry >= 0 && h.dist < best->dist) {
+                best->dist = h.dist; best->t = h.t; best->ent = e; best->entry = h.entry;
             }
         }
     }
-    return best_ent;
+}
+
+// Rebuilds the ColliderResult of the winning entity: position (sphere.rs:39 / triangle.rs:53),
+// normal (sphere.rs:45 / the triangle's stored normal, triangle.rs:54), material.
+RRT_DEV void finish_hit(const DScene& sc, V3 o, V3 d, const Closest& c, Hit* h) {
+    h->hit = c.ent >= 0;
+    h->tri = -1; h->mat = -1; h->t = 0.0;
+    h->pos = mk(0., 0., 0.); h->normal = mk(0., 0., 0.);
+    if (!h->hit) return;
+    const DEntity ent = sc.ents[c.ent];
+    h->t = c.t;
+    h->pos = o + d * c.t;
+    if (ent.kind == 0) {
+        const DSphere* S = sc.spheres + ent.index;
+        h->normal = normalize(h->pos - ld3(S->c));
+        h->mat = S->material;
+    } else {
+        const DMesh* M = sc.meshes + ent.index;
+        const int32_t id = as_global(M->leaf_refs)[c.entry];
+        h->tri = id;
+        h->normal = ld3g(as_global(M->normals) + 3 * (size_t)id);
+        h->mat = M->material;
+    }
 }
 
 // cubemap() + CubemapBehavior::compute (cubemap.rs:84-164, 56-77)
@@ -385,15 +542,19 @@ RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y
 }
 
 // One cast() (tracer.rs:177-211) of path `path` at depth `bounce`.
-template <bool PRIMARY>
-RRT_DEV void process_ray(const DScene& sc, const DWork& wk, const DFrame& fr, bool active, uint32_t path, V3 o, V3 d,
-                         uint32_t bounce, int32_t* d_ids, double* d_t, uint32_t pixel, bool aov) {
+template <bool PRIMARY, int CULL>
+RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk, const DFrame& fr, bool active,
+                         uint32_t path, V3 o, V3 d, uint32_t bounce, int32_t* d_ids, double* d_t, uint32_t pixel,
+                         bool aov) {
     const uint64_t P = wk.cap;
     bool cont = false;
     V3 ro = mk(0., 0., 0.), rd = mk(0., 0., 0.);
     if (active) {
+        Closest c;
+        closest_hit<CULL>(sc, lnodes, o, d, &c, wk.stats);
         Hit h;
-        const int32_t ent = closest_hit(sc, o, d, &h, wk.stats);
+        finish_hit(sc, o, d, c, &h);
+        const int32_t ent = c.ent;
         if (PRIMARY && aov) {
             if (d_ids) { d_ids[2 * (size_t)pixel] = ent; d_ids[2 * (size_t)pixel + 1] = h.tri; }
             if (d_t) d_t[pixel] = h.hit ? h.t : 0.0;
@@ -437,20 +598,47 @@ RRT_DEV void process_ray(const DScene& sc, const DWork& wk, const DFrame& fr, bo
     }
 }
 
-__global__ __launch_bounds__(256) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
-    const uint32_t path = blockIdx.x * 256u + threadIdx.x;   // grid covers ns * npx_local exactly
-    const uint32_t s_local = path / fr.npx_local, lp = path - s_local * fr.npx_local;
-    uint32_t x = 0, y = 0;
-    const bool active = local_pixel(fr, lp, &x, &y);
-    const uint32_t sample = fr.s0 + s_local;
-    V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-    if (active) primary_ray(fr, x, y, sample, &o, &d);
-    process_ray<true>(sc, wk, fr, active, path, o, d, 0u, d_ids, d_t, y * fr.width + x, sample == 0u);
+// Copies the descent array of scene.lds_mesh into LDS (all threads of the block; ends with a barrier).
+// Returns the LDS pointer, or nullptr when nothing is staged.
+RRT_DEV const DNodeI* stage_nodes(const DScene& sc, unsigned char* smem) {
+    if (sc.lds_mesh < 0) return nullptr;
+    const DMesh M = sc.meshes[sc.lds_mesh];
+    const RRT_GLOBAL double* src = (const RRT_GLOBAL double*)M.nodes;   // 16 B = 2 doubles per node
+    double* dst = (double*)smem;
+    for (int32_t i = threadIdx.x; i < 2 * sc.lds_nodes; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    return (const DNodeI*)smem;
 }
 
-__global__ __launch_bounds__(256) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
+// Persistent blocks: block b takes path tiles b, b + grid, ... (neighbouring tiles, which cost
+// about the same, go to different blocks), so the LDS staging is paid once per block.
+template <int CULL>
+__global__ __launch_bounds__(256, 4) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const DNodeI* lnodes = stage_nodes(sc, smem);
+    const uint32_t n_chunks = (uint32_t)(((uint64_t)fr.ns * fr.npx_local) >> 8);   // 256 paths per chunk, exact
+    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        const uint32_t path = chunk * 256u + threadIdx.x;
+        const uint32_t s_local = path / fr.npx_local, lp = path - s_local * fr.npx_local;
+        uint32_t x = 0, y = 0;
+        const bool active = local_pixel(fr, lp, &x, &y);
+        const uint32_t sample = fr.s0 + s_local;
+        V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
+        if (active) primary_ray(fr, x, y, sample, &o, &d);
+        process_ray<true, CULL>(sc, lnodes, wk, fr, active, path, o, d, 0u, d_ids, d_t, y * fr.width + x, sample == 0u);
+    }
+}
+
+template <int CULL>
+__global__ __launch_bounds__(256, 4) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
+    extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = wk.q_count[bounce];
     const uint32_t stride = gridDim.x * 256u;
+    if (blockIdx.x * 256u >= count) {          // whole block idle (block-uniform): skip the staging too
+        if (blockIdx.x == 0 && threadIdx.x == 0 && bounce < 4u) atomicAdd(&wk.stats[4 + bounce], 0ull);
+        return;
+    }
+    const DNodeI* lnodes = stage_nodes(sc, smem);
     const uint64_t P = wk.cap;
     const DQueue& q = wk.q[bounce & 1];
     // every lane of a wave runs the same number of iterations (queue_slot uses wave-wide ops)
@@ -465,7 +653,7 @@ __global__ __launch_bounds__(256) void k_wave_bounce(DScene sc, DWork wk, DFrame
             d = mk(q.d[i], q.d[i + P], q.d[i + 2 * P]);
             path = q.path[i];
         }
-        process_ray<false>(sc, wk, fr, active, path, o, d, bounce, nullptr, nullptr, 0u, false);
+        process_ray<false, CULL>(sc, lnodes, wk, fr, active, path, o, d, bounce, nullptr, nullptr, 0u, false);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&wk.stats[0], (unsigned long long)count);
@@ -528,8 +716,13 @@ __global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* ray
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
+    Closest c;
+    if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, &c, stats);
+    else if (sc.cull_mode == 1) closest_hit<1>(sc, nullptr, o, d, &c, stats);
+    else closest_hit<2>(sc, nullptr, o, d, &c, stats);
     Hit h;
-    const int32_t e = closest_hit(sc, o, d, &h, stats);
+    finish_hit(sc, o, d, c, &h);
+    const int32_t e = c.ent;
     if (ent) ent[i] = e;
     if (tri) tri[i] = h.tri;
     if (t) t[i] = h.hit ? h.t : 0.0;
@@ -548,8 +741,11 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
     uint32_t bounce = 0;
     V3 col;
     for (;;) {
+        Closest c;
+        if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, &c, stats);
+        else closest_hit<2>(sc, nullptr, o, d, &c, stats);
         Hit h;
-        closest_hit(sc, o, d, &h, stats);
+        finish_hit(sc, o, d, c, &h);
         if (!h.hit) { col = sky_color(sc, d); break; }
         const DMaterial m = sc.mats[h.mat];
         V3 A, Pm;
@@ -577,17 +773,20 @@ __global__ void k_selftest(int op, const double* a, const double* b, int64_t n, 
     out[i] = r;
 }
 
-inline uint32_t bounce_grid() { return 256u * 8u; }   // 256 CUs x 8 blocks of 256 threads
+inline uint32_t trace_grid() { return 256u * 8u; }   // 256 CUs x 8 blocks of 256 threads
+inline size_t lds_bytes(const DScene& sc) { return sc.lds_mesh >= 0 ? (size_t)sc.lds_nodes * sizeof(DNodeI) : 0; }
 
 }  // namespace
 
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
-    const uint64_t paths = (uint64_t)fr.ns * fr.npx_local;
-    hipLaunchKernelGGL(k_wave_primary, dim3((uint32_t)(paths / 256)), dim3(256), 0, (hipStream_t)stream, sc, wk, fr,
-                       d_ids, d_t);
+    const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
+    const uint32_t grid = (uint32_t)(chunks < trace_grid() ? chunks : trace_grid());
+    auto k = sc.cull_mode == 0 ? k_wave_primary<0> : sc.cull_mode == 1 ? k_wave_primary<1> : k_wave_primary<2>;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, d_ids, d_t);
 }
 void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream) {
-    hipLaunchKernelGGL(k_wave_bounce, dim3(bounce_grid()), dim3(256), 0, (hipStream_t)stream, sc, wk, fr, bounce);
+    auto k = sc.cull_mode == 0 ? k_wave_bounce<0> : sc.cull_mode == 1 ? k_wave_bounce<1> : k_wave_bounce<2>;
+    hipLaunchKernelGGL(k, dim3(trace_grid()), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
 }
 void launch_accumulate(const DWork& wk, const DFrame& fr, void* stream) {
     hipLaunchKernelGGL(k_accumulate, dim3(fr.npx_local / 256), dim3(256), 0, (hipStream_t)stream, wk, fr);

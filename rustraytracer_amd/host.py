@@ -123,6 +123,9 @@ class World:
     def set_work_budget(self, nbytes):
         B.check(B.lib.rrt_set_work_budget(self.h, int(nbytes)))
 
+    def set_cull_mode(self, mode):
+        B.check(B.lib.rrt_set_cull_mode(self.h, int(mode)))
+
     def commit(self):
         B.check(B.lib.rrt_scene_commit(self.h))
 
