@@ -180,6 +180,35 @@ def test_incomplete_scene_is_an_error(H):
         w.render(16, 16)
 
 
+def test_conservative_cull_is_exact(H, O, scenes):
+    """The f32 triangle cull must never skip a triangle the exact f64 test accepts: mode 2 runs
+    both and counts disagreements; modes 0 (no cull, literal kdtree.rs:203-212), 1 and 2 give
+    identical results on coherent frames and on incoherent rays incl. far-away origins."""
+    c = scenes.main_rs_scene(O.OracleScene(), O)
+    rng = np.random.default_rng(21)
+    rays = _random_rays(rng, 300000)
+    far = _random_rays(rng, 50000)
+    far[:, :3] *= 1e4                                  # origins ~1e6 away: pad grows, cull must stay safe
+    d = np.array([0.0, 10.0, 70.0]) - far[:, :3]
+    far[:, 3:] = d * (1.0 / np.sqrt((d[:, 0] ** 2 + d[:, 1] ** 2) + d[:, 2] ** 2))[:, None]
+    grazing = _random_rays(rng, 50000, spread=2.0)     # many rays through the same few leaves
+    rays = np.concatenate([rays, far, grazing])
+    want = c.trace_rays(rays)
+    frame = c.render(640, 360, spp=2, seed=5)
+    for mode in (0, 1, 2):
+        g = scenes.main_rs_scene(H.World(device=0), H.loaders)
+        g.set_cull_mode(mode)
+        got = g.trace_rays(rays)
+        for k in ("ent", "tri", "t", "pos", "normal"):
+            assert np.array_equal(got[k], want[k]), (mode, k)
+        out = g.render(640, 360, spp=2, seed=5)
+        _same(out, frame)
+        assert out["stats"]["cull_violations"] == 0
+        if mode == 2:
+            big = g.render(1920, 1080, spp=2, seed=1, want=("rgb",))
+            assert big["stats"]["cull_violations"] == 0
+
+
 def test_tile_sharding_assembles_to_full_frame(main_pair, H):
     """The N-GPU path on one GPU: each rank's compact tile buffer, concatenated
     in rank order (what the RCCL all-gather produces), de-interleaves to the
