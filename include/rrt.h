@@ -120,6 +120,19 @@ void rrt_scene_destroy(rrt_scene* s);
 int rrt_add_material(rrt_scene* s, const double color[3], double albedo, double lambert_mix,
                      double reflective_mix, double phong_mix, int32_t alpha);
 
+/* EXTENSION (no reference counterpart; BASELINE configs[2..4] ask for refraction and stochastic
+ * diffuse bounces, which the reference lacks -- SURVEY §0).  Same three shader slots, but slot [1],
+ * the continuation lobe, is chosen: lobe 0 = Reflection (identical to rrt_add_material),
+ * 1 = Refraction with index `ior` (Snell; total internal reflection mirrors; a ray refracted into
+ * a sphere travels "inside" it and meets that sphere's FAR root, because sphere.rs:28-47 only
+ * returns the near one), 2 = DiffuseBounce: direction normalize(n + uniform sphere point) drawn
+ * from Philox4x32-10(counter = {pixel, sample, bounce, 1+attempt}, key = seed) by Marsaglia's
+ * trig-free rejection.  colour += cast(continuation) * lobe_mix, under the same
+ * `bounce <= max_bounce` rule and summation order as the Reflection slot (tracer.rs:194-202).
+ * One continuation lobe per material keeps every path a non-branching chain. */
+int rrt_add_material_ext(rrt_scene* s, const double color[3], double albedo, double lambert_mix, double lobe_mix,
+                         double phong_mix, int32_t alpha, int32_t lobe, double ior);
+
 /* Sphere::new(position, radius, material) + world.entities.push
  * (src/geometry/sphere.rs:17-24, src/main.rs:62).  Returns the entity id =
  * insertion order, as the reference's entity list. */

@@ -56,6 +56,7 @@ def lib():
         L.orc_set_sort_mode.argtypes = [C.c_int]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
         L.orc_add_material.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, C.c_double, C.c_int]
+        L.orc_add_material_ext.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
         L.orc_add_sphere.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_int]
         L.orc_add_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_set_sky_face.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]
@@ -185,6 +186,9 @@ class OracleScene:
 
     def add_material(self, color, albedo, lambert, reflective, phong, alpha):
         return self.L.orc_add_material(self.h, _d3(color), albedo, lambert, reflective, phong, int(alpha))
+
+    def add_material_ext(self, color, albedo, lambert, lobe_mix, phong, alpha, lobe, ior=1.0):
+        return self.L.orc_add_material_ext(self.h, _d3(color), albedo, lambert, lobe_mix, phong, int(alpha), int(lobe), float(ior))
 
     def add_sphere(self, center, radius, mat):
         return self.L.orc_add_sphere(self.h, _d3(center), float(radius), mat)

@@ -116,10 +116,15 @@ inline void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
 // ---------------------------------------------------------------------------
 // Scene types.
 // ---------------------------------------------------------------------------
-struct Ray { V3 o, d; uint32_t bounce; };            // common.rs:17-21
+// common.rs:17-21, plus the extension state a continuation ray carries: the sphere entity it
+// travels inside (refraction lobe; -1 = none) -- reference rays always have medium = -1.
+struct Ray { V3 o, d; uint32_t bounce; int medium = -1; };
 
-struct Material {                                     // material.rs:20-33
-    V3 color; double albedo, mixL, mixR, mixP; int alpha;
+// material.rs:20-33.  Extension: the continuation lobe in shader slot [1] is the reference's
+// Reflection (lobe 0), a Refraction (lobe 1, index of refraction ior) or a cosine-weighted
+// DiffuseBounce (lobe 2); mixR is that lobe's mix().  Exactly one continuation lobe per material.
+struct Material {
+    V3 color; double albedo, mixL, mixR, mixP; int alpha; int lobe = 0; double ior = 1.0;
 };
 
 struct Collide {                                      // common.rs:49-54 (+ids, t)
@@ -410,6 +415,27 @@ inline Collide sphere_collide(const Sphere& s, const Ray& ray) {
     return r;
 }
 
+// Extension: sphere the ray is travelling inside (after a refraction into it): the FAR root.
+// (sphere.rs:28-47 returns the near root even when it lies behind the origin, SURVEY Q8, so
+// a ray that starts inside a sphere could never leave it.)
+inline Collide sphere_collide_inside(const Sphere& s, const Ray& ray) {
+    Collide none;
+    const V3 l = sub(s.c, ray.o);
+    const double tca = dot(l, ray.d);
+    const double d2 = mag2(l) - tca * tca;
+    if (d2 > s.r2) return none;
+    const double thc = std::sqrt(s.r2 - d2);
+    const double t = tca + thc;
+    if (!(t > 0.0)) return none;
+    Collide r;
+    r.hit = true;
+    r.t = t;
+    r.pos = add(ray.o, mul(ray.d, t));
+    r.normal = normalize(sub(r.pos, s.c));
+    r.mat = s.mat; r.tri = -1;
+    return r;
+}
+
 struct Entity { int kind; int index; };  // kind 0 = sphere, 1 = mesh
 struct Face { std::vector<uint8_t> rgb; uint32_t w = 0, h = 0; };
 
@@ -468,7 +494,11 @@ inline Collide closest_hit(const Scene& sc, const Ray& ray, int* ent_out, Counte
     Collide best; int best_ent = -1;
     for (size_t e = 0; e < sc.ents.size(); ++e) {
         Collide r;
-        if (sc.ents[e].kind == 0) { ++c.sphere_tests; r = sphere_collide(sc.spheres[sc.ents[e].index], ray); }
+        if (sc.ents[e].kind == 0) {
+            ++c.sphere_tests;
+            r = ((int)e == ray.medium) ? sphere_collide_inside(sc.spheres[sc.ents[e].index], ray)
+                                       : sphere_collide(sc.spheres[sc.ents[e].index], ray);
+        }
         else r = kd_collide(*sc.meshes[sc.ents[e].index], ray, c);
         if (r.hit) {
             const double dist = mag2(sub(r.pos, ray.o));
@@ -480,7 +510,66 @@ inline Collide closest_hit(const Scene& sc, const Ray& ray, int* ent_out, Counte
 }
 
 // tracer.rs:177-211 ; lambert.rs:22-45 ; reflection.rs:19-44 ; phong.rs:25-47
-V3 cast(const Scene& sc, const Settings& st, const Ray& ray, Counters& c, Primary* prim) {
+// Extension lobes (no reference counterpart).  All arithmetic is +,-,*,/,sqrt so that the GPU
+// reproduces it bit for bit.
+// Uniform point on the unit sphere, Marsaglia (1972): rejection in the unit disc, no trig.
+inline V3 sphere_point(const Settings& st, uint32_t pixel, uint32_t sample, uint32_t bounce, V3 fallback) {
+    const uint32_t key[2] = {(uint32_t)st.seed, (uint32_t)(st.seed >> 32)};
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint32_t ctr[4] = {pixel, sample, bounce, 1u + j};
+        uint32_t r[4];
+        philox4x32_10(ctr, key, r);
+        for (int h = 0; h < 2; ++h) {
+            const double x1 = (double)r[2 * h] * (1.0 / 2147483648.0) - 1.0;
+            const double x2 = (double)r[2 * h + 1] * (1.0 / 2147483648.0) - 1.0;
+            const double s2 = x1 * x1 + x2 * x2;
+            if (s2 < 1.0) {
+                const double w = 2.0 * std::sqrt(1.0 - s2);
+                return V3{x1 * w, x2 * w, 1.0 - 2.0 * s2};
+            }
+        }
+    }
+    return fallback;
+}
+
+// Continuation ray of a hit for the material's lobe.
+inline Ray continuation(const Settings& st, const Material& m, const Ray& ray, const Collide& hit, int ent_kind,
+                        int ent, uint32_t pixel, uint32_t sample) {
+    Ray out;
+    out.bounce = ray.bounce + 1;
+    out.medium = ray.medium;
+    const V3 n = hit.normal;
+    if (m.lobe == 0) {                               // reflection.rs:29-33, 42-44
+        out.o = add(hit.pos, mul(n, 0.3));
+        out.d = normalize(sub(ray.d, mul(mul(n, dot(n, ray.d)), 2.0)));
+        return out;
+    }
+    const double cosi = dot(n, ray.d);
+    const bool entering = cosi < 0.0;
+    const V3 nn = entering ? n : neg(n);             // normal facing the incoming ray
+    if (m.lobe == 1) {                               // refraction (Snell), total internal reflection -> mirror
+        const double cc = entering ? -cosi : cosi;
+        const double eta = entering ? 1.0 / m.ior : m.ior;
+        const double k = 1.0 - eta * eta * (1.0 - cc * cc);
+        if (k < 0.0) {
+            out.o = add(hit.pos, mul(nn, 0.3));
+            out.d = normalize(sub(ray.d, mul(mul(nn, dot(nn, ray.d)), 2.0)));
+        } else {
+            out.o = sub(hit.pos, mul(nn, 0.3));
+            out.d = normalize(add(mul(ray.d, eta), mul(nn, eta * cc - std::sqrt(k))));
+            out.medium = (entering && ent_kind == 0) ? ent : -1;
+        }
+        return out;
+    }
+    // lobe 2: cosine-weighted diffuse bounce = normalize(nn + uniform sphere point)
+    const V3 sp = sphere_point(st, pixel, sample, ray.bounce, nn);
+    out.o = add(hit.pos, mul(nn, 0.3));
+    out.d = normalize(add(nn, sp));
+    return out;
+}
+
+V3 cast(const Scene& sc, const Settings& st, const Ray& ray, Counters& c, Primary* prim, uint32_t pixel = 0,
+        uint32_t sample = 0) {
     ++c.rays;
     int ent;
     const Collide hit = closest_hit(sc, ray, &ent, c);
@@ -501,12 +590,8 @@ V3 cast(const Scene& sc, const Settings& st, const Ray& ray, Counters& c, Primar
         }
         // shaders[1] = Reflection
         if (!(ray.bounce > st.max_bounce) && !(st.prune_zero_mix && m.mixR == 0.0)) {
-            Ray refl;
-            refl.o = add(hit.pos, mul(hit.normal, 0.3));
-            const V3 r = sub(ray.d, mul(mul(hit.normal, dot(hit.normal, ray.d)), 2.0));
-            refl.d = normalize(r);
-            refl.bounce = ray.bounce + 1;
-            const V3 col = cast(sc, st, refl, c, nullptr);
+            const Ray refl = continuation(st, m, ray, hit, sc.ents[ent].kind, ent, pixel, sample);
+            const V3 col = cast(sc, st, refl, c, nullptr, pixel, sample);
             final_color = add(final_color, mul(col, m.mixR));
         }
         // shaders[2] = Phong
@@ -560,7 +645,13 @@ void orc_scene_destroy(void* h) { delete (Scene*)h; }
 
 int orc_add_material(void* h, const double color[3], double albedo, double mixL, double mixR, double mixP, int alpha) {
     Scene* s = (Scene*)h;
-    s->mats.push_back(Material{V3{color[0], color[1], color[2]}, albedo, mixL, mixR, mixP, alpha});
+    s->mats.push_back(Material{V3{color[0], color[1], color[2]}, albedo, mixL, mixR, mixP, alpha, 0, 1.0});
+    return (int)s->mats.size() - 1;
+}
+int orc_add_material_ext(void* h, const double color[3], double albedo, double mixL, double lobe_mix, double mixP,
+                         int alpha, int lobe, double ior) {
+    Scene* s = (Scene*)h;
+    s->mats.push_back(Material{V3{color[0], color[1], color[2]}, albedo, mixL, lobe_mix, mixP, alpha, lobe, ior});
     return (int)s->mats.size() - 1;
 }
 
@@ -684,7 +775,7 @@ void orc_cast_rays(void* h, const double* rays, int64_t n, uint32_t max_bounce, 
     Counters c;
     for (int64_t i = 0; i < n; ++i) {
         Ray r{V3{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, V3{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]}, 0};
-        V3 col = cast(*s, st, r, c, nullptr);
+        V3 col = cast(*s, st, r, c, nullptr, (uint32_t)i, 0u);   // RNG stream of ray i: pixel = i, sample 0, seed 0
         color[3 * i] = col.x; color[3 * i + 1] = col.y; color[3 * i + 2] = col.z;
     }
 }
@@ -720,7 +811,7 @@ int orc_render(void* h, const Camera* cam, const Settings* stp, int64_t y0, int6
                         sample_jitter(st, (uint32_t)i, sp, &jx, &jy);
                         const Ray r = primary_ray(*cam, st, x, (uint32_t)y, jx, jy);
                         Primary prim;
-                        const V3 col = cast(*s, st, r, c, sp == 0 ? &prim : nullptr);
+                        const V3 col = cast(*s, st, r, c, sp == 0 ? &prim : nullptr, (uint32_t)i, sp);
                         if (sp == 0) {
                             sum = col;
                             if (out_ids) { out_ids[2 * i] = prim.ent; out_ids[2 * i + 1] = prim.tri; }

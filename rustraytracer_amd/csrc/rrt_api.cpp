@@ -100,7 +100,7 @@ struct rrt_scene {
     rrt::DScene dscene{};
 
     // work buffers
-    DevBuf w_qo[2], w_qd[2], w_qpath[2], w_qcount, w_recA, w_recP, w_recR, w_samp, w_accum, w_stats;
+    DevBuf w_qo[2], w_qd[2], w_qpath[2], w_qmed[2], w_qcount, w_recA, w_recP, w_recR, w_samp, w_accum, w_stats;
     DevBuf w_ids, w_t, w_color, w_rgb;  // staging for the host-output render
 
     // timing of the last render
@@ -258,7 +258,7 @@ struct FramePlan {
 size_t bytes_per_path(uint32_t levels) {
     return (size_t)levels * 7 * 8   // recA + recP + recR
            + 3 * 8                  // samp
-           + 2 * (6 * 8 + 4);       // two queues
+           + 2 * (6 * 8 + 4 + 4);   // two queues
 }
 
 int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, FramePlan* out) {
@@ -316,7 +316,9 @@ int ensure_work(rrt_scene* s, const FramePlan& pl, rrt::DWork* wk) {
         HIP_TRY(s->w_qpath[i].ensure(P * 4));
         wk->q[i].o = s->w_qo[i].as<double>();
         wk->q[i].d = s->w_qd[i].as<double>();
+        HIP_TRY(s->w_qmed[i].ensure(P * 4));
         wk->q[i].path = s->w_qpath[i].as<uint32_t>();
+        wk->q[i].medium = s->w_qmed[i].as<int32_t>();
     }
     HIP_TRY(s->w_qcount.ensure((rrt::kMaxLevels + 1) * 4));
     HIP_TRY(s->w_recA.ensure(P * 3 * 8 * pl.levels));
@@ -448,10 +450,23 @@ void rrt_scene_destroy(rrt_scene* s) {
     delete s;
 }
 
+int rrt_add_material_ext(rrt_scene* s, const double color[3], double albedo, double lambert_mix, double lobe_mix,
+                         double phong_mix, int32_t alpha, int32_t lobe, double ior) {
+    if (lobe < 0 || lobe > 2) return fail(RRT_E_INVALID, "lobe must be 0 (reflection), 1 (refraction) or 2 (diffuse)");
+    if (lobe == 1 && !(ior > 0.0)) return fail(RRT_E_INVALID, "index of refraction must be > 0");
+    const int id = rrt_add_material(s, color, albedo, lambert_mix, lobe_mix, phong_mix, alpha);
+    if (id < 0) return id;
+    s->mats[(size_t)id].lobe = lobe;
+    s->mats[(size_t)id].ior = ior;
+    return id;
+}
+
 int rrt_add_material(rrt_scene* s, const double color[3], double albedo, double lambert_mix, double reflective_mix,
                      double phong_mix, int32_t alpha) {
     if (!s || !color) return fail(RRT_E_INVALID, "null argument");
     rrt::DMaterial m{};
+    m.lobe = 0;
+    m.ior = 1.0;
     for (int a = 0; a < 3; ++a) m.color[a] = color[a];
     m.albedo = albedo;
     m.mixL = lambert_mix;

@@ -80,12 +80,16 @@ struct DSphere {
     int32_t pad;
 };
 
+// Material::new_lambert_material's three shaders (material.rs:28-32) in fixed slots.  Slot [1] is
+// the continuation lobe: 0 = Reflection (the reference), 1 = Refraction(ior), 2 = DiffuseBounce
+// (extensions, see include/rrt.h); mixR is that lobe's mix().
 struct DMaterial {
     double color[3];
     double albedo;
     double mixL, mixR, mixP;
     int32_t alpha;
-    int32_t pad;
+    int32_t lobe;
+    double ior;
 };
 
 struct DEntity {
@@ -120,6 +124,7 @@ struct DQueue {
     double* o;        // [3][cap]
     double* d;        // [3][cap]
     uint32_t* path;   // [cap]
+    int32_t* medium;  // [cap] sphere entity the ray travels inside, -1 = none
 };
 
 // Wavefront work buffers for one batch of P paths.

@@ -392,6 +392,21 @@ RRT_DEV bool sphere_collide(const DSphere* __restrict__ S, V3 o, V3 d, double* t
     return true;
 }
 
+// EXTENSION: the sphere the ray travels inside (entered through a Refraction lobe) answers with
+// its far root; sphere.rs:28-47 only ever returns the near one.
+RRT_DEV bool sphere_collide_inside(const DSphere* __restrict__ S, V3 o, V3 d, double* tout) {
+    const V3 l = ld3(S->c) - o;
+    const double tca = dot(l, d);
+    const double d2 = mag2(l) - tca * tca;
+    const double r2 = S->r2;
+    if (d2 > r2) return false;
+    const double thc = sqrt(r2 - d2);
+    const double t = tca + thc;
+    if (!(t > 0.0)) return false;
+    *tout = t;
+    return true;
+}
+
 struct Closest {
     double dist, t;
     int32_t ent;     // entity id, -1 = miss
@@ -400,7 +415,7 @@ struct Closest {
 
 // The entity loop of RayTracer::cast (tracer.rs:178-190)
 template <int CULL>
-RRT_DEV void closest_hit(const DScene& sc, const DNodeI* lnodes, V3 o, V3 d, Closest* best,
+RRT_DEV void closest_hit(const DScene& sc, const DNodeI* lnodes, V3 o, V3 d, int32_t medium, Closest* best,
                          unsigned long long* stats) {
     const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);   // aabb.rs:74, same for every box test of this ray
     best->dist = kF64Max; best->t = 0.0; best->ent = -1; best->entry = -1;
@@ -408,7 +423,9 @@ RRT_DEV void closest_hit(const DScene& sc, const DNodeI* lnodes, V3 o, V3 d, Clo
         const DEntity ent = sc.ents[e];
         if (ent.kind == 0) {
             double t;
-            if (sphere_collide(sc.spheres + ent.index, o, d, &t)) {
+            const bool got = (e == medium) ? sphere_collide_inside(sc.spheres + ent.index, o, d, &t)
+                                           : sphere_collide(sc.spheres + ent.index, o, d, &t);
+            if (got) {
                 const V3 pos = o + d * t;                  // sphere.rs:39
                 const double dist = mag2(pos - o);         // tracer.rs:184
                 if (dist < best->dist) { best->dist = dist; best->t = t; best->ent = e; best->entry = -1; }
@@ -491,10 +508,55 @@ RRT_DEV void shade_direct(const DScene& sc, const DMaterial& m, V3 d, V3 normal,
     *Pm = ph * m.mixP;
 }
 
-// reflection.rs:29-33, 42-44
-RRT_DEV void reflect_ray(V3 pos, V3 normal, V3 d, V3* ro, V3* rd) {
-    *ro = pos + normal * 0.3;
-    *rd = normalize(d - (normal * dot(normal, d)) * 2.0);
+// EXTENSION: uniform point on the unit sphere, Marsaglia's rejection in the unit disc (no trig,
+// so CPU oracle and GPU agree bit for bit).  Philox counter {pixel, sample, bounce, 1 + attempt}.
+RRT_DEV V3 sphere_point(const DFrame& fr, uint32_t pixel, uint32_t sample, uint32_t bounce, V3 fallback) {
+    for (uint32_t j = 0; j < 4u; ++j) {
+        uint32_t r[4];
+        philox4x32_10(pixel, sample, bounce, 1u + j, fr.seed_lo, fr.seed_hi, r);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double x1 = (double)r[2 * h] * (1.0 / 2147483648.0) - 1.0;
+            const double x2 = (double)r[2 * h + 1] * (1.0 / 2147483648.0) - 1.0;
+            const double s2 = x1 * x1 + x2 * x2;
+            if (s2 < 1.0) {
+                const double w = 2.0 * sqrt(1.0 - s2);
+                return mk(x1 * w, x2 * w, 1.0 - 2.0 * s2);
+            }
+        }
+    }
+    return fallback;
+}
+
+// Continuation ray of a hit for the material's lobe: Reflection is reflection.rs:29-33, 42-44;
+// Refraction and DiffuseBounce are the extensions documented at rrt_add_material_ext.
+RRT_DEV void continuation(const DFrame& fr, const DMaterial& m, V3 pos, V3 n, V3 d, bool ent_is_sphere, int32_t ent,
+                          uint32_t bounce, uint32_t pixel, uint32_t sample, V3* ro, V3* rd, int32_t* medium) {
+    if (m.lobe == 0) {
+        *ro = pos + n * 0.3;
+        *rd = normalize(d - (n * dot(n, d)) * 2.0);
+        return;
+    }
+    const double cosi = dot(n, d);
+    const bool entering = cosi < 0.0;
+    const V3 nn = entering ? n : neg(n);
+    if (m.lobe == 1) {
+        const double cc = entering ? -cosi : cosi;
+        const double eta = entering ? 1.0 / m.ior : m.ior;
+        const double k = 1.0 - eta * eta * (1.0 - cc * cc);
+        if (k < 0.0) {
+            *ro = pos + nn * 0.3;
+            *rd = normalize(d - (nn * dot(nn, d)) * 2.0);
+        } else {
+            *ro = pos - nn * 0.3;
+            *rd = normalize(d * eta + nn * (eta * cc - sqrt(k)));
+            *medium = (entering && ent_is_sphere) ? ent : -1;
+        }
+        return;
+    }
+    const V3 sp = sphere_point(fr, pixel, sample, bounce, nn);
+    *ro = pos + nn * 0.3;
+    *rd = normalize(nn + sp);
 }
 
 // Wave-aggregated queue append: one atomic per wave.
@@ -544,14 +606,15 @@ RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y
 // One cast() (tracer.rs:177-211) of path `path` at depth `bounce`.
 template <bool PRIMARY, int CULL>
 RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk, const DFrame& fr, bool active,
-                         uint32_t path, V3 o, V3 d, uint32_t bounce, int32_t* d_ids, double* d_t, uint32_t pixel,
-                         bool aov) {
+                         uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
+                         uint32_t pixel, uint32_t sample) {
     const uint64_t P = wk.cap;
+    const bool aov = sample == 0u;
     bool cont = false;
     V3 ro = mk(0., 0., 0.), rd = mk(0., 0., 0.);
     if (active) {
         Closest c;
-        closest_hit<CULL>(sc, lnodes, o, d, &c, wk.stats);
+        closest_hit<CULL>(sc, lnodes, o, d, medium, &c, wk.stats);
         Hit h;
         finish_hit(sc, o, d, c, &h);
         const int32_t ent = c.ent;
@@ -570,7 +633,8 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
                 wk.recA[r] = A.x; wk.recA[r + P] = A.y; wk.recA[r + 2 * P] = A.z;
                 wk.recP[r] = Pm.x; wk.recP[r + P] = Pm.y; wk.recP[r + 2 * P] = Pm.z;
                 wk.recR[(size_t)bounce * P + path] = m.mixR;
-                reflect_ray(h.pos, h.normal, d, &ro, &rd);
+                continuation(fr, m, h.pos, h.normal, d, sc.ents[ent].kind == 0, ent, bounce, pixel, sample, &ro, &rd,
+                             &medium);
             } else {
                 col = A + Pm;   // Reflection returned None (reflection.rs:26-28) or was pruned
             }
@@ -595,6 +659,7 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
         q.o[slot] = ro.x; q.o[slot + P] = ro.y; q.o[slot + 2 * P] = ro.z;
         q.d[slot] = rd.x; q.d[slot + P] = rd.y; q.d[slot + 2 * P] = rd.z;
         q.path[slot] = path;
+        q.medium[slot] = medium;
     }
 }
 
@@ -625,7 +690,7 @@ __global__ __launch_bounds__(256, 4) void k_wave_primary(DScene sc, DWork wk, DF
         const uint32_t sample = fr.s0 + s_local;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         if (active) primary_ray(fr, x, y, sample, &o, &d);
-        process_ray<true, CULL>(sc, lnodes, wk, fr, active, path, o, d, 0u, d_ids, d_t, y * fr.width + x, sample == 0u);
+        process_ray<true, CULL>(sc, lnodes, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample);
     }
 }
 
@@ -647,13 +712,21 @@ __global__ __launch_bounds__(256, 4) void k_wave_bounce(DScene sc, DWork wk, DFr
     for (uint32_t r = 0; r < rounds; ++r, i += stride) {
         const bool active = i < count;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-        uint32_t path = 0;
+        uint32_t path = 0, pixel = 0, sample = 0;
+        int32_t medium = -1;
         if (active) {
             o = mk(q.o[i], q.o[i + P], q.o[i + 2 * P]);
             d = mk(q.d[i], q.d[i + P], q.d[i + 2 * P]);
             path = q.path[i];
+            medium = q.medium[i];
+            // the RNG stream of the diffuse lobe is keyed by the global pixel and sample of the path
+            const uint32_t s_local = path / fr.npx_local;
+            uint32_t x = 0, y = 0;
+            local_pixel(fr, path - s_local * fr.npx_local, &x, &y);
+            pixel = y * fr.width + x;
+            sample = fr.s0 + s_local;
         }
-        process_ray<false, CULL>(sc, lnodes, wk, fr, active, path, o, d, bounce, nullptr, nullptr, 0u, false);
+        process_ray<false, CULL>(sc, lnodes, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, pixel, sample);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&wk.stats[0], (unsigned long long)count);
@@ -717,9 +790,9 @@ __global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* ray
     if (i >= n) return;
     const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
     Closest c;
-    if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, &c, stats);
-    else if (sc.cull_mode == 1) closest_hit<1>(sc, nullptr, o, d, &c, stats);
-    else closest_hit<2>(sc, nullptr, o, d, &c, stats);
+    if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, -1, &c, stats);
+    else if (sc.cull_mode == 1) closest_hit<1>(sc, nullptr, o, d, -1, &c, stats);
+    else closest_hit<2>(sc, nullptr, o, d, -1, &c, stats);
     Hit h;
     finish_hit(sc, o, d, c, &h);
     const int32_t e = c.ent;
@@ -739,11 +812,13 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
     V3 sA[kMaxLevels], sP[kMaxLevels];
     double sR[kMaxLevels];
     uint32_t bounce = 0;
+    int32_t medium = -1;
+    DFrame fr{};                 // RNG stream of ray i: pixel = i, sample 0, seed 0 (as the oracle's cast_rays)
     V3 col;
     for (;;) {
         Closest c;
-        if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, &c, stats);
-        else closest_hit<2>(sc, nullptr, o, d, &c, stats);
+        if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, medium, &c, stats);
+        else closest_hit<2>(sc, nullptr, o, d, medium, &c, stats);
         Hit h;
         finish_hit(sc, o, d, c, &h);
         if (!h.hit) { col = sky_color(sc, d); break; }
@@ -754,7 +829,8 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
         if (!cont) { col = A + Pm; break; }
         sA[bounce] = A; sP[bounce] = Pm; sR[bounce] = m.mixR;
         V3 ro, rd;
-        reflect_ray(h.pos, h.normal, d, &ro, &rd);
+        continuation(fr, m, h.pos, h.normal, d, sc.ents[c.ent].kind == 0, c.ent, bounce, (uint32_t)i, 0u, &ro, &rd,
+                     &medium);
         o = ro; d = rd; ++bounce;
     }
     for (uint32_t k = bounce; k-- > 0;) col = (sA[k] + col * sR[k]) + sP[k];

@@ -96,6 +96,10 @@ class World:
     def add_material(self, color, albedo, lambert, reflective, phong, alpha):
         return B.check(B.lib.rrt_add_material(self.h, _d3(color), albedo, lambert, reflective, phong, int(alpha)))
 
+    def add_material_ext(self, color, albedo, lambert, lobe_mix, phong, alpha, lobe, ior=1.0):
+        return B.check(B.lib.rrt_add_material_ext(self.h, _d3(color), albedo, lambert, lobe_mix, phong, int(alpha),
+                                                  int(lobe), float(ior)))
+
     def add_sphere(self, center, radius, mat):
         return B.check(B.lib.rrt_add_sphere(self.h, _d3(center), float(radius), mat))
 

@@ -63,3 +63,89 @@ def cfg2_scene(b, loaders):
     (ufo_fix.obj kd-tree + the two spheres; diffuse+specular material of
     main.rs:50) under the blue_sunset cubemap (6 x 2048^2)."""
     return main_rs_scene(b, loaders, skybox="blue_sunset")
+
+
+# ---------------------------------------------------------------------------
+# Extension configs (BASELINE configs[2..4]).  The reference has no refraction, no stochastic
+# bounce and no synthetic mesh; these scenes exercise the build's documented extensions
+# (include/rrt.h: rrt_add_material_ext) and are checked GPU-vs-oracle only.
+# ---------------------------------------------------------------------------
+LOBE_REFLECT, LOBE_REFRACT, LOBE_DIFFUSE = 0, 1, 2
+
+
+def cfg3_scene(b, loaders):
+    """configs[2]: reflect/refract glass-sphere scene, deterministic bounces (render with
+    max_bounce=8, spp=1): a mirror sphere, two glass spheres (ior 1.5 / 1.33), a tinted
+    half-mirror and a large matte ground sphere, blue_sunset sky."""
+    empty_world(b, loaders, "blue_sunset")
+    mirror = b.add_material(color_vec(0, 0, 0), 0.8, 0.0, 1.0, 0.1, 20)
+    glass = b.add_material_ext(color_vec(10, 10, 10), 0.8, 0.05, 0.95, 0.3, 20, LOBE_REFRACT, 1.5)
+    water = b.add_material_ext(color_vec(10, 20, 30), 0.8, 0.05, 0.9, 0.2, 20, LOBE_REFRACT, 1.33)
+    tinted = b.add_material(color_vec(200, 80, 60), 0.9, 0.7, 0.3, 0.2, 20)
+    matte = b.add_material(color_vec(90, 110, 90), 1.0, 1.0, 0.0, 0.0, 20)
+    b.add_sphere((0.0, 0.0, 9.0), 1.6, glass)
+    b.add_sphere((-3.6, 0.3, 8.0), 1.3, mirror)
+    b.add_sphere((3.4, 0.6, 8.5), 1.2, water)
+    b.add_sphere((1.2, -1.2, 5.5), 0.6, tinted)
+    b.add_sphere((0.0, 1002.0, 9.0), 1000.0, matte)      # world +y is image-down: a floor
+    return b
+
+
+def cfg4_scene(b, loaders):
+    """configs[3]: the UFO scene with a stochastic diffuse bounce on the UFO (path tracing)."""
+    empty_world(b, loaders, "blue_sunset")
+    mat1 = b.add_material(color_vec(100, 100, 200), 0.8, 1.0, 0.01, 0.1, 20)
+    mat2 = b.add_material(color_vec(0, 0, 0), 0.8, 0.0, 1.0, 0.1, 20)
+    ufo = b.add_material_ext(color_vec(100, 100, 50), 1.0, 0.6, 0.5, 0.3, 20, LOBE_DIFFUSE)
+    verts, normals = loaders.load_model(os.path.join(ASSETS, "obj", "ufo_fix.obj"), (0.0, 30.0, 70.0), (1.0, -1.0, 1.0))
+    b.add_mesh(verts, normals, ufo)
+    b.add_sphere((-3.0, 0.0, 5.0), 1.0, mat1)
+    b.add_sphere((2.0, 0.0, 8.0), 1.0, mat2)
+    return b
+
+
+def heightfield_mesh(n=1000, seed=1):
+    """configs[4]'s synthetic mesh: an n x n jittered height-field grid (2 triangles per cell,
+    2*n*n in total) over x,y in [-50,50], facing the camera around z = 90; heights from a seeded
+    integer hash, vertices rounded to f32 like an OBJ loader would, flat geometric normals."""
+    import numpy as np
+    g = n + 1
+    ix, iy = np.meshgrid(np.arange(g, dtype=np.uint64), np.arange(g, dtype=np.uint64), indexing="xy")
+
+    def hash01(a, b, s):
+        h = (a * np.uint64(0x9E3779B97F4A7C15) + b * np.uint64(0xC2B2AE3D27D4EB4F) + np.uint64(s) * np.uint64(0x165667B19E3779F9))
+        h ^= h >> np.uint64(29)
+        h *= np.uint64(0xBF58476D1CE4E5B9)
+        h ^= h >> np.uint64(32)
+        return (h & np.uint64(0xFFFFFF)).astype(np.float64) / float(1 << 24)
+
+    cell = 100.0 / n
+    x = -50.0 + ix.astype(np.float64) * cell + (hash01(ix, iy, seed) - 0.5) * 0.3 * cell
+    y = -50.0 + iy.astype(np.float64) * cell + (hash01(ix, iy, seed + 1) - 0.5) * 0.3 * cell
+    # smooth bumps from a coarse lattice + fine roughness
+    cx, cy = ix // np.uint64(max(n // 16, 1)), iy // np.uint64(max(n // 16, 1))
+    fx = (ix % np.uint64(max(n // 16, 1))).astype(np.float64) / max(n // 16, 1)
+    fy = (iy % np.uint64(max(n // 16, 1))).astype(np.float64) / max(n // 16, 1)
+    c00, c10 = hash01(cx, cy, seed + 2), hash01(cx + np.uint64(1), cy, seed + 2)
+    c01, c11 = hash01(cx, cy + np.uint64(1), seed + 2), hash01(cx + np.uint64(1), cy + np.uint64(1), seed + 2)
+    sx, sy = fx * fx * (3 - 2 * fx), fy * fy * (3 - 2 * fy)
+    coarse = (c00 * (1 - sx) + c10 * sx) * (1 - sy) + (c01 * (1 - sx) + c11 * sx) * sy
+    z = 90.0 + 12.0 * (coarse - 0.5) + 0.5 * cell * (hash01(ix, iy, seed + 3) - 0.5)
+    P = np.stack([x, y, z], axis=-1).astype(np.float32).astype(np.float64)
+    p00, p10, p01, p11 = P[:-1, :-1], P[:-1, 1:], P[1:, :-1], P[1:, 1:]
+    t1 = np.stack([p00, p10, p11], axis=2)
+    t2 = np.stack([p00, p11, p01], axis=2)
+    verts = np.concatenate([t1.reshape(-1, 3, 3), t2.reshape(-1, 3, 3)], axis=0)
+    nrm = np.cross(verts[:, 1] - verts[:, 0], verts[:, 2] - verts[:, 0])
+    nrm = nrm * (1.0 / np.sqrt((nrm[:, 0] * nrm[:, 0] + nrm[:, 1] * nrm[:, 1]) + nrm[:, 2] * nrm[:, 2]))[:, None]
+    nrm[nrm[:, 2] > 0] *= -1.0          # face the camera (which looks along +z)
+    return np.ascontiguousarray(verts), np.ascontiguousarray(nrm)
+
+
+def cfg5_scene(b, loaders, n=1000):
+    """configs[4]: synthetic 2*n*n-triangle mesh (n=1000 -> 2M), diffuse bounces, sky cubemap."""
+    empty_world(b, loaders, "sky")
+    rough = b.add_material_ext(color_vec(150, 140, 120), 1.0, 0.7, 0.5, 0.1, 20, LOBE_DIFFUSE)
+    verts, normals = heightfield_mesh(n)
+    b.add_mesh(verts, normals, rough)
+    return b
