@@ -1,0 +1,137 @@
+// =============================================================================
+// rrt_host.hpp -- header-only C++ host mirror of the reference's scene API over
+// the C ABI (include/rrt.h, include/rrt_host.h), so that src/main.rs can be
+// restated line for line without Rust (examples/main.cpp).  Names and argument
+// order follow the reference; each item cites what it mirrors.  No tracing
+// happens here: everything below RayTracer::render is librrt.so on the GPU.
+// =============================================================================
+#pragma once
+#include <chrono>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rrt_host.h"
+
+namespace rrt_host {
+
+struct Vector3 { double x, y, z; };
+using Point3 = Vector3;
+
+// common.rs:87-93
+inline Vector3 color_vec(unsigned char r, unsigned char g, unsigned char b) {
+    return Vector3{(double)r / 255.0, (double)g / 255.0, (double)b / 255.0};
+}
+
+inline void check(int rc) {
+    if (rc < 0) throw std::runtime_error(std::string("rrt: ") + rrt_last_error());   // the reference unwrap()s
+}
+
+// material.rs:13-43.  A value type, like the reference's (Material: Clone).
+struct Material {
+    Vector3 color; double albedo, lambert, reflective, phong; int alpha;
+    int lobe = 0; double ior = 1.0;            // extension (rrt_add_material_ext)
+    // Material::new_lambert_material(color, albedo, lambert, reflective, phong, alpha)   material.rs:20-33
+    static Material new_lambert_material(Vector3 color, double albedo, double lambert, double reflective,
+                                         double phong, int alpha) {
+        return Material{color, albedo, lambert, reflective, phong, alpha};
+    }
+};
+
+// common.rs:41-47: the closed set of entities the reference ships.
+struct Sphere {                                  // sphere.rs:17-24
+    Point3 position; double radius; Material material;
+    static Sphere new_(Point3 position, double radius, Material material) { return Sphere{position, radius, material}; }
+};
+struct Model {                                   // model.rs:24-56
+    std::string path; Material material; Point3 position; Vector3 scale;
+    static Model new_(const std::string& path, Material material, Point3 position, Vector3 scale) {
+        std::printf("Opening model @ %s\n", path.c_str());   // model.rs:25
+        return Model{path, material, position, scale};
+    }
+};
+
+// common.rs:10-15 + RayTracer::new_empty_world (tracer.rs:53-75)
+class World {
+  public:
+    World() : h_(rrt_scene_create()) { if (!h_) throw std::runtime_error("rrt_scene_create failed"); }
+    ~World() { rrt_scene_destroy(h_); }
+    World(const World&) = delete;
+    World& operator=(const World&) = delete;
+    World(World&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+
+    // world.entities.push(Box::new(sphere))     main.rs:62
+    int push(const Sphere& s) {
+        const double c[3] = {s.position.x, s.position.y, s.position.z};
+        const int id = rrt_add_sphere(h_, c, s.radius, material_id(s.material));
+        check(id);
+        return id;
+    }
+    // world.entities.push(Box::new(model))      main.rs:61
+    int push(const Model& m) {
+        const double p[3] = {m.position.x, m.position.y, m.position.z}, sc[3] = {m.scale.x, m.scale.y, m.scale.z};
+        const int id = rrt_host_add_model(h_, m.path.c_str(), material_id(m.material), p, sc);
+        check(id);
+        return id;
+    }
+    rrt_scene* raw() const { return h_; }
+
+  private:
+    friend class RayTracer;
+    int material_id(const Material& m) {
+        const double c[3] = {m.color.x, m.color.y, m.color.z};
+        const int id = m.lobe == 0 ? rrt_add_material(h_, c, m.albedo, m.lambert, m.reflective, m.phong, m.alpha)
+                                   : rrt_add_material_ext(h_, c, m.albedo, m.lambert, m.reflective, m.phong, m.alpha,
+                                                          m.lobe, m.ior);
+        check(id);
+        return id;
+    }
+    rrt_scene* h_;
+};
+
+// tracer.rs:11-24
+class RayTracer {
+  public:
+    // RayTracer::new_default_renderer((w, h))   tracer.rs:38-51
+    static RayTracer new_default_renderer(unsigned w, unsigned h) {
+        RayTracer r;
+        rrt_default_camera(&r.camera_);
+        rrt_default_settings(&r.settings_, w, h);
+        return r;
+    }
+    // RayTracer::new_empty_world(skybox)        tracer.rs:53-75
+    static World new_empty_world(const std::string& skybox) {
+        World w;
+        const double dir[3] = {1.0, -1.0, 1.0};
+        const Vector3 lc = color_vec(230, 230, 230);
+        const double col[3] = {lc.x, lc.y, lc.z};
+        check(rrt_set_directional_light(w.raw(), dir, col, 2.0));
+        std::printf("\nLoading assets...");                   // cubemap.rs:17
+        check(rrt_host_load_cubemap(w.raw(), skybox.c_str()));
+        std::printf(".......\n");
+        check(rrt_set_ambient(w.raw(), 0.15));
+        return w;
+    }
+    rrt_settings& settings() { return settings_; }
+    // raytracer.render(output, world)           tracer.rs:77-175
+    void render(const std::string& output, World& world) {
+        std::printf("Rendering...\n");
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<unsigned char> img((size_t)settings_.width * settings_.height * 3);
+        check(rrt_render(world.raw(), &camera_, &settings_, img.data(), nullptr, nullptr, nullptr));
+        if (rrt_host_save_png_rgb8(output.c_str(), img.data(), settings_.width, settings_.height) == 0)
+            std::printf("Saved!\n");
+        else
+            std::printf("%s\n", rrt_last_error());            // tracer.rs:167-170: the error is printed and swallowed
+        std::printf("\n\n");
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0);
+        std::printf("Finished in %lldms\n", (long long)ms.count());
+    }
+
+  private:
+    rrt_camera camera_{};
+    rrt_settings settings_{};
+};
+
+}  // namespace rrt_host

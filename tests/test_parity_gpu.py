@@ -334,3 +334,20 @@ def test_cfg5_synthetic_mesh(H, O, scenes):
         assert np.array_equal(big[k][rows], cb[k][rows]), k
     tri = big["ids"][..., 1]
     assert tri.max() < 2000000 and len(np.unique(tri[tri >= 0])) > 100000
+
+
+def test_cpp_host_main_rs_writes_bruh_png(golden_dir, tmp_path):
+    """examples/main.cpp = src/main.rs restated on the C++ host mirror (include/rrt_host.hpp);
+    the PNG it writes through the C ABI must decode to the reference's bruh.png."""
+    import subprocess
+    from PIL import Image
+    root = os.path.dirname(golden_dir.rstrip("/").rsplit("/tests", 1)[0] + "/x")
+    exe = os.path.join(root, "examples", "rrt_main")
+    assert os.path.exists(exe), "build with `make -C examples` (done by __graft_entry__.build())"
+    out = str(tmp_path / "bruh.png")
+    r = subprocess.run([exe, out], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Model has" not in r.stderr and "Saved!" in r.stdout and "Finished in" in r.stdout
+    got = np.asarray(Image.open(out).convert("RGB"))
+    gold = np.asarray(Image.open(os.path.join(golden_dir, "bruh.png")).convert("RGB"))
+    assert np.array_equal(got, gold)
