@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librrt.so")
+LIB_PATH = os.environ.get("RRT_LIB", os.path.join(_HERE, "librrt.so"))   # RRT_LIB: timing-probe builds only
 
 
 class RrtError(RuntimeError):

@@ -723,6 +723,9 @@ int rrt_selftest_math(int op, const double* a, const double* b, int64_t n, doubl
     return RRT_OK;
 }
 
+// not part of include/rrt.h: timing-probe builds only (tools/phase_probe.py)
+void rrt_debug_phases(unsigned long long out[16]) { rrt::debug_phases(out); }
+
 void rrt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     rrt::philox4x32_10_host(ctr, key, out);
 }

@@ -165,6 +165,7 @@ void launch_cast_rays(const DScene& sc, const double* d_rays, int64_t n, uint32_
                       double* color, unsigned long long* stats, void* stream);
 void launch_selftest(int op, const double* a, const double* b, int64_t n, double* out, void* stream);
 
+void debug_phases(unsigned long long out[16]);   // zeros unless built with -DRRT_PROBE=1
 void philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 }  // namespace rrt

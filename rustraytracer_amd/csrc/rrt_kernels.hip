@@ -14,12 +14,37 @@
 // =============================================================================
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "rrt_device.h"
 
 namespace rrt {
 namespace {
 
 #define RRT_DEV __device__ __forceinline__
+
+// Diagnostic build only (-DRRT_PROBE=1): per-phase wave-cycle accounting with s_memtime stamps.
+// Each lane accumulates the cycles it spends per phase; a chunk adds the lane-maximum per phase
+// to g_phase[].  The shipped build (RRT_PROBE 0) contains none of this.
+#ifndef RRT_PROBE
+#define RRT_PROBE 0
+#endif
+#if RRT_PROBE
+__device__ unsigned long long g_phase[16];
+struct Phases {
+    unsigned long long t, acc[8];
+};
+__device__ Phases* g_dummy;
+#define PH_ARG , Phases& ph
+#define PH_PASS , ph
+#define PH_DUMMY , ph_dummy
+#define PH(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph.acc[i] += now_ - ph.t; ph.t = now_; } while (0)
+#else
+#define PH_ARG
+#define PH_PASS
+#define PH_DUMMY
+#define PH(i) do { } while (0)
+#endif
 
 struct V3 {
     double x, y, z;
@@ -303,22 +328,24 @@ RRT_DEV void leaf_test(const TriData& T, int32_t entry, V3 o, V3 d, LeafBest* b)
 
 template <int CULL>
 RRT_DEV void cull_or_test(const Box32& b, const RRT_GLOBAL DTri* tri, int32_t entry, V3 o, V3 d, const CullRay& cr,
-                          LeafBest* best, unsigned long long* stats) {
+                          LeafBest* best, unsigned long long* stats PH_ARG) {
     const bool keep = cull_keep(b, cr);
     if (keep || CULL == 2) {
+        PH(4);
         const TriData T = ld_tri(tri);
         if (CULL == 2 && !keep) {   // verify mode: the exact test must agree that this entry is not a hit
             double t;
             if (tri_collide(T, o, d, &t)) atomicAdd(&stats[2], 1ull);
         }
         leaf_test(T, entry, o, d, best);
+        PH(5);
     }
 }
 
 // KDTree::collide (kdtree.rs:192-235).  Returns the winning stream entry in out->entry (-1 = miss).
 template <int CULL>
 RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, V3 inv, LeafBest* out,
-                          unsigned long long* stats) {
+                          unsigned long long* stats PH_ARG) {
     out->entry = -1; out->dist = kF64Max; out->t = 0.0;
     V3 point;
     {
@@ -338,7 +365,12 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, V3 i
             return;
         }
         const RRT_GLOBAL DLeaf* L = leaves + leaf;
+        PH(2);
         const int32_t first = L->first, count = L->count;
+#if RRT_PROBE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        PH(3);
         LeafBest best;
         best.dist = kF64Max; best.t = 0.0; best.entry = -1;
         const RRT_GLOBAL DTri* tp = stream + first;
@@ -361,11 +393,12 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, V3 i
             Box32 A = ld_box32(bp);
             for (int32_t k = 0; k < count; k += 2) {
                 const Box32 B = ld_box32(bp + (k + 1 < last ? k + 1 : last));
-                cull_or_test<CULL>(A, tp + k, first + k, o, d, cr, &best, stats);
+                cull_or_test<CULL>(A, tp + k, first + k, o, d, cr, &best, stats PH_PASS);
                 A = ld_box32(bp + (k + 2 < last ? k + 2 : last));
-                if (k + 1 < count) cull_or_test<CULL>(B, tp + k + 1, first + k + 1, o, d, cr, &best, stats);
+                if (k + 1 < count) cull_or_test<CULL>(B, tp + k + 1, first + k + 1, o, d, cr, &best, stats PH_PASS);
             }
         }
+        PH(4);
         if (best.entry >= 0) {
             *out = best;
             return;
@@ -375,6 +408,7 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, V3 i
         const int32_t nb = L->rope[get_plane(point, mn, mx)];
         if (nb < 0) return;
         leaf = find_point(M, lnodes, nb, point);
+        PH(6);
     }
 }
 
@@ -416,7 +450,7 @@ struct Closest {
 // The entity loop of RayTracer::cast (tracer.rs:178-190)
 template <int CULL>
 RRT_DEV void closest_hit(const DScene& sc, const DNodeI* lnodes, V3 o, V3 d, int32_t medium, Closest* best,
-                         unsigned long long* stats) {
+                         unsigned long long* stats PH_ARG) {
     const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);   // aabb.rs:74, same for every box test of this ray
     best->dist = kF64Max; best->t = 0.0; best->ent = -1; best->entry = -1;
     for (int32_t e = 0; e < sc.n_ents; ++e) {
@@ -433,7 +467,9 @@ RRT_DEV void closest_hit(const DScene& sc, const DNodeI* lnodes, V3 o, V3 d, int
         } else {
             const DMesh M = sc.meshes[ent.index];
             LeafBest h;
-            mesh_collide<CULL>(M, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, inv, &h, stats);
+            PH(1);
+            mesh_collide<CULL>(M, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, inv, &h, stats PH_PASS);
+            PH(2);
             // same |pos - origin|^2 as the leaf-level metric (kdtree.rs:206 == tracer.rs:184)
             if (h.entry >= 0 && h.dist < best->dist) {
                 best->dist = h.dist; best->t = h.t; best->ent = e; best->entry = h.entry;
@@ -614,7 +650,13 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
     V3 ro = mk(0., 0., 0.), rd = mk(0., 0., 0.);
     if (active) {
         Closest c;
-        closest_hit<CULL>(sc, lnodes, o, d, medium, &c, wk.stats);
+#if RRT_PROBE
+        Phases ph;
+        for (int q_ = 0; q_ < 8; ++q_) ph.acc[q_] = 0;
+        ph.t = __builtin_amdgcn_s_memtime();
+#endif
+        closest_hit<CULL>(sc, lnodes, o, d, medium, &c, wk.stats PH_PASS);
+        PH(1);
         Hit h;
         finish_hit(sc, o, d, c, &h);
         const int32_t ent = c.ent;
@@ -652,6 +694,18 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
             }
             wk.samp[path] = col.x; wk.samp[path + P] = col.y; wk.samp[path + 2 * P] = col.z;
         }
+#if RRT_PROBE
+        PH(7);
+        for (int q_ = 0; q_ < 8; ++q_) atomicMax(&g_phase[8 + q_], ph.acc[q_]);      // (debug) keeps them live
+        for (int q_ = 0; q_ < 8; ++q_) {
+            unsigned long long m_ = ph.acc[q_];
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o_ = __shfl_xor(m_, off, 64);
+                m_ = o_ > m_ ? o_ : m_;
+            }
+            if (__lane_id() == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_phase[q_], m_);
+        }
+#endif
     }
     const uint32_t slot = queue_slot(&wk.q_count[bounce + 1], cont);
     if (cont) {
@@ -788,11 +842,14 @@ __global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* ray
                                                     unsigned long long* stats) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+#if RRT_PROBE
+    Phases ph_dummy{};
+#endif
     const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
     Closest c;
-    if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, -1, &c, stats);
-    else if (sc.cull_mode == 1) closest_hit<1>(sc, nullptr, o, d, -1, &c, stats);
-    else closest_hit<2>(sc, nullptr, o, d, -1, &c, stats);
+    if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, -1, &c, stats PH_DUMMY);
+    else if (sc.cull_mode == 1) closest_hit<1>(sc, nullptr, o, d, -1, &c, stats PH_DUMMY);
+    else closest_hit<2>(sc, nullptr, o, d, -1, &c, stats PH_DUMMY);
     Hit h;
     finish_hit(sc, o, d, c, &h);
     const int32_t e = c.ent;
@@ -808,6 +865,9 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
                                                    uint32_t prune, double* color, unsigned long long* stats) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+#if RRT_PROBE
+    Phases ph_dummy{};
+#endif
     V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
     V3 sA[kMaxLevels], sP[kMaxLevels];
     double sR[kMaxLevels];
@@ -817,8 +877,8 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
     V3 col;
     for (;;) {
         Closest c;
-        if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, medium, &c, stats);
-        else closest_hit<2>(sc, nullptr, o, d, medium, &c, stats);
+        if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, medium, &c, stats PH_DUMMY);
+        else closest_hit<2>(sc, nullptr, o, d, medium, &c, stats PH_DUMMY);
         Hit h;
         finish_hit(sc, o, d, c, &h);
         if (!h.hit) { col = sky_color(sc, d); break; }
@@ -849,7 +909,17 @@ __global__ void k_selftest(int op, const double* a, const double* b, int64_t n, 
     out[i] = r;
 }
 
-inline uint32_t trace_grid() { return 256u * 8u; }   // 256 CUs x 8 blocks of 256 threads
+// Persistent grid of the trace kernels: 256 CUs x 32 blocks of 256 threads -- 8 rounds of resident
+// blocks, so the hardware block scheduler evens out the tail (measured: 1024/2048 blocks 3.27 ms,
+// 8192 blocks 3.12 ms per cfg2 frame).  RRT_TRACE_GRID overrides, for tuning.
+inline uint32_t trace_grid() {
+    static const uint32_t g = [] {
+        const char* e = getenv("RRT_TRACE_GRID");
+        const long v = e ? atol(e) : 0;
+        return (uint32_t)(v > 0 && v <= 65535 ? v : 256 * 32);
+    }();
+    return g;
+}
 inline size_t lds_bytes(const DScene& sc) { return sc.lds_mesh >= 0 ? (size_t)sc.lds_nodes * sizeof(DNodeI) : 0; }
 
 }  // namespace
@@ -890,6 +960,15 @@ void launch_cast_rays(const DScene& sc, const double* d_rays, int64_t n, uint32_
 void launch_selftest(int op, const double* a, const double* b, int64_t n, double* out, void* stream) {
     hipLaunchKernelGGL(k_selftest, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, n,
                        out);
+}
+void debug_phases(unsigned long long out[16]) {
+#if RRT_PROBE
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), 16 * sizeof(unsigned long long));
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
+#else
+    for (int i = 0; i < 16; ++i) out[i] = 0;
+#endif
 }
 void philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
