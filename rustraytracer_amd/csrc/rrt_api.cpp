@@ -165,7 +165,12 @@ int commit(rrt_scene* s) {
         HIP_TRY(m.d_refs.upload(T.leaf_refs.data(), T.leaf_refs.size() * sizeof(int32_t)));
         std::vector<rrt::DTri> stream(T.leaf_refs.size());
         for (size_t j = 0; j < stream.size(); ++j) stream[j] = m.tris[(size_t)T.leaf_refs[j]];
-        HIP_TRY(m.d_tris.upload(stream.data(), stream.size() * sizeof(rrt::DTri)));
+        {
+            // the leaf loop prefetches up to kStreamPad entries past a leaf: keep them readable
+            std::vector<rrt::DTri> padded(stream);
+            padded.resize(stream.size() + rrt::kStreamPad, stream.empty() ? rrt::DTri{} : stream.back());
+            HIP_TRY(m.d_tris.upload(padded.data(), padded.size() * sizeof(rrt::DTri)));
+        }
         // outward-rounded f32 boxes of the stream entries + the cull constants
         std::vector<rrt::DBox32> cull(stream.size());
         double edge_max = 0.0;
@@ -178,13 +183,14 @@ int commit(rrt_scene* s) {
                 float flo = (float)lo, fhi = (float)hi;
                 if ((double)flo > lo) flo = std::nextafterf(flo, -INFINITY);
                 if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
-                cull[j].mn[a] = std::nextafterf(flo, -INFINITY);   // one more ulp for the p0+e rounding
-                cull[j].mx[a] = std::nextafterf(fhi, INFINITY);
+                cull[j].v[2 * a] = std::nextafterf(flo, -INFINITY);   // one more ulp for the p0+e rounding
+                cull[j].v[2 * a + 1] = std::nextafterf(fhi, INFINITY);
                 l1 += t.e1[a] * t.e1[a];
                 l2 += t.e2[a] * t.e2[a];
             }
             edge_max = std::fmax(edge_max, std::sqrt(std::fmax(l1, l2)));
         }
+        cull.resize(stream.size() + rrt::kStreamPad, cull.empty() ? rrt::DBox32{} : cull.back());
         HIP_TRY(m.d_cull.upload(cull.data(), cull.size() * sizeof(rrt::DBox32)));
         dm[i].cull = m.d_cull.as<rrt::DBox32>();
         dm[i].edge_max = edge_max * (1.0 + 1e-9);
@@ -724,7 +730,7 @@ int rrt_selftest_math(int op, const double* a, const double* b, int64_t n, doubl
 }
 
 // not part of include/rrt.h: timing-probe builds only (tools/phase_probe.py)
-void rrt_debug_phases(unsigned long long out[16]) { rrt::debug_phases(out); }
+void rrt_debug_phases(unsigned long long out[32]) { rrt::debug_phases(out); }
 
 void rrt_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     rrt::philox4x32_10_host(ctr, key, out);

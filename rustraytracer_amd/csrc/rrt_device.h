@@ -51,8 +51,7 @@ struct DTri {
 
 // f32 bounding box of one triangle-stream entry, rounded outward (cull test only).
 struct DBox32 {
-    float mn[3];
-    float mx[3];
+    float v[6];   // mn.x, mx.x, mn.y, mx.y, mn.z, mx.z  (axis pairs, as the packed-f32 slab test reads them)
 };
 
 struct DMesh {
@@ -64,6 +63,7 @@ struct DMesh {
                                 // leaf, so a leaf's triangles are contiguous and the next one can be prefetched)
     const double* normals;  // 3 per triangle (indexed by triangle id)
     const DBox32* cull;     // per stream entry, see "conservative cull" in rrt_kernels.hip
+                            // (tris and cull carry kStreamPad extra entries for the prefetch to run into)
     int32_t material;
     int32_t n_nodes;
     // constants of the conservative cull (host-computed, f64)
@@ -117,6 +117,7 @@ struct DScene {
     int32_t pad0;
 };
 
+constexpr int32_t kStreamPad = 4;        // readable entries past the end of DMesh::tris / DMesh::cull
 constexpr int32_t kMaxLdsNodes = 3072;   // 48 KB of LDS per 256-thread block at most
 
 // Ray queue, SoA.  cap entries each.
@@ -165,7 +166,7 @@ void launch_cast_rays(const DScene& sc, const double* d_rays, int64_t n, uint32_
                       double* color, unsigned long long* stats, void* stream);
 void launch_selftest(int op, const double* a, const double* b, int64_t n, double* out, void* stream);
 
-void debug_phases(unsigned long long out[16]);   // zeros unless built with -DRRT_PROBE=1
+void debug_phases(unsigned long long out[32]);   // zeros unless built with -DRRT_PROBE=1
 void philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 }  // namespace rrt

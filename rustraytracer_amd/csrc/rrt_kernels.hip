@@ -23,27 +23,28 @@ namespace {
 
 #define RRT_DEV __device__ __forceinline__
 
-// Diagnostic build only (-DRRT_PROBE=1): per-phase wave-cycle accounting with s_memtime stamps.
-// Each lane accumulates the cycles it spends per phase; a chunk adds the lane-maximum per phase
-// to g_phase[].  The shipped build (RRT_PROBE 0) contains none of this.
+// Diagnostic build only (-DRRT_PROBE=1): wave-level event counters.  CNT(i) adds, once per wave
+// that reaches it, 1 to g_phase[2i] and the number of active lanes to g_phase[2i+1]; with the
+// static instruction counts of the blocks in the ISA this gives the issue budget of a frame
+// (tools/phase_probe.py).  The shipped build (RRT_PROBE 0) contains none of this.
+#ifndef RRT_WAVES
+#define RRT_WAVES 4   // waves per SIMD the trace kernels are register-bounded for
+#endif
 #ifndef RRT_PROBE
 #define RRT_PROBE 0
 #endif
 #if RRT_PROBE
-__device__ unsigned long long g_phase[16];
-struct Phases {
-    unsigned long long t, acc[8];
-};
-__device__ Phases* g_dummy;
-#define PH_ARG , Phases& ph
-#define PH_PASS , ph
-#define PH_DUMMY , ph_dummy
-#define PH(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph.acc[i] += now_ - ph.t; ph.t = now_; } while (0)
+__device__ unsigned long long g_phase[32];
+#define CNT(i)                                                                          \
+    do {                                                                                \
+        const unsigned long long m_ = __ballot(1);                                      \
+        if ((int)__lane_id() == __ffsll((long long)m_) - 1) {                           \
+            atomicAdd(&g_phase[2 * (i)], 1ull);                                         \
+            atomicAdd(&g_phase[2 * (i) + 1], (unsigned long long)__popcll(m_));         \
+        }                                                                               \
+    } while (0)
 #else
-#define PH_ARG
-#define PH_PASS
-#define PH_DUMMY
-#define PH(i) do { } while (0)
+#define CNT(i) do { } while (0)
 #endif
 
 struct V3 {
@@ -227,6 +228,7 @@ RRT_DEV int32_t find_point(const DMesh& M, const DNodeI* lnodes, int32_t at, V3 
     if (lnodes) {
         DNodeI n = lnodes[at];
         while (n.axis >= 0) {
+            CNT(3);
             at = (comp(p, n.axis) >= n.split) ? n.right : at + 1;   // pre-order: left child = at + 1
             n = lnodes[at];
         }
@@ -266,42 +268,55 @@ RRT_DEV int get_plane(V3 p, V3 mn, V3 mx) {
 // comparison; every rounding errs towards "keep".  cull_mode 2 runs both tests and counts
 // disagreements (expected and tested: 0).
 // ---------------------------------------------------------------------------
-struct F3 {
-    float x, y, z;
-};
+// The slab test itself runs on packed f32 pairs (v_pk_fma_f32): per axis i one fused multiply-add
+// gives t0 = mn_i*inv_i + c0_i and t1 = mx_i*inv_i + c1_i, where the per-ray constants
+//     c0_i = -(o_i + pad)*inv_i - sgn(inv_i)*K_i,     c1_i = -(o_i - pad)*inv_i + sgn(inv_i)*K_i
+// are formed in f64 and rounded once.  K_i = 2^-21 (|o_i| + pad) |inv_i| is 4x the absolute error
+// of that form (the f32 rounding of c and of inv against the product o_i*inv_i; the fma itself
+// adds only a relative 2^-24, inside the 2^-18 relative slack), applied so that the entry time
+// moves down and the exit time up.  An infinite inv_i (d_i = 0) makes t0/t1 NaN or a harmless
+// infinity (never entry = +inf or exit = -inf): v_min/v_max drop NaN operands, so that axis
+// simply stops constraining the interval.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct CullRay {
-    F3 om, op, inv;   // origin + pad, origin - pad, 1/d
-    float tmin;       // -(bound on dt)
+    f32x2 c[3];     // (c0_i, c1_i)
+    float inv[3];
+    float tmin;     // -(bound on dt)
 };
 
-RRT_DEV CullRay make_cull_ray(const DMesh& M, V3 o, V3 d) {
+RRT_DEV CullRay make_cull_ray(const DMesh& M, V3 o, V3 d, V3 inv) {
     const double dl = fabs(d.x) + fabs(d.y) + fabs(d.z);                       // >= |d|
     const double R = fabs(o.x - M.center[0]) + fabs(o.y - M.center[1]) + fabs(o.z - M.center[2]) + M.radius;
     const double S = M.edge_max;
     const double omax = fmax(fabs(o.x), fmax(fabs(o.y), fabs(o.z)));
-    const double pad = 2.5e-7 * S * S * dl * (R + S) + 0x1p-20 * (omax + M.abs_max);
-    const float padf = (float)(pad * 1.000001) + 1e-30f;
+    const double pad = (2.5e-7 * S * S * dl * (R + S) + 0x1p-20 * (omax + M.abs_max)) * 1.000001 + 1e-300;
     CullRay c;
-    const float ox = (float)o.x, oy = (float)o.y, oz = (float)o.z;
-    c.om = F3{ox + padf, oy + padf, oz + padf};
-    c.op = F3{ox - padf, oy - padf, oz - padf};
-    c.inv = F3{1.0f / (float)d.x, 1.0f / (float)d.y, 1.0f / (float)d.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double oi = comp(o, i), ii = comp(inv, i);
+        const double K = 0x1p-21 * (fabs(oi) + pad) * fabs(ii);
+        const double sK = ii < 0.0 ? -K : K;
+        c.c[i] = f32x2{(float)(-((oi + pad) * ii) - sK), (float)(-((oi - pad) * ii) + sK)};
+        c.inv[i] = (float)ii;
+    }
     c.tmin = -((float)(8e-8 * S * S * (R + S) * 1.000001) + 1e-30f);
     return c;
 }
 
 struct Box32 {
-    float a0, a1, a2, b0, b1, b2;
+    f32x2 p[3];     // (mn_i, mx_i)
 };
-RRT_DEV Box32 ld_box32(const RRT_GLOBAL DBox32* p) { return Box32{p->mn[0], p->mn[1], p->mn[2], p->mx[0], p->mx[1], p->mx[2]}; }
+RRT_DEV Box32 ld_box32(const RRT_GLOBAL DBox32* b) {
+    return Box32{{f32x2{b->v[0], b->v[1]}, f32x2{b->v[2], b->v[3]}, f32x2{b->v[4], b->v[5]}}};
+}
 
 // true = keep (the exact test must run).  NaN-safe: any NaN comparison falls to "keep".
 RRT_DEV bool cull_keep(const Box32& b, const CullRay& c) {
-    const float t0x = (b.a0 - c.om.x) * c.inv.x, t1x = (b.b0 - c.op.x) * c.inv.x;
-    const float t0y = (b.a1 - c.om.y) * c.inv.y, t1y = (b.b1 - c.op.y) * c.inv.y;
-    const float t0z = (b.a2 - c.om.z) * c.inv.z, t1z = (b.b2 - c.op.z) * c.inv.z;
-    const float tlo = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-    const float thi = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    const f32x2 tx = __builtin_elementwise_fma(b.p[0], f32x2{c.inv[0], c.inv[0]}, c.c[0]);
+    const f32x2 ty = __builtin_elementwise_fma(b.p[1], f32x2{c.inv[1], c.inv[1]}, c.c[1]);
+    const f32x2 tz = __builtin_elementwise_fma(b.p[2], f32x2{c.inv[2], c.inv[2]}, c.c[2]);
+    const float tlo = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fminf(tz.x, tz.y));
+    const float thi = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fmaxf(tz.x, tz.y));
     const float hi = thi + 0x1p-18f * (fabsf(tlo) + fabsf(thi));
     return !(hi < tlo) && !(hi < c.tmin);
 }
@@ -326,36 +341,23 @@ RRT_DEV void leaf_test(const TriData& T, int32_t entry, V3 o, V3 d, LeafBest* b)
     }
 }
 
-template <int CULL>
-RRT_DEV void cull_or_test(const Box32& b, const RRT_GLOBAL DTri* tri, int32_t entry, V3 o, V3 d, const CullRay& cr,
-                          LeafBest* best, unsigned long long* stats PH_ARG) {
-    const bool keep = cull_keep(b, cr);
-    if (keep || CULL == 2) {
-        PH(4);
-        const TriData T = ld_tri(tri);
-        if (CULL == 2 && !keep) {   // verify mode: the exact test must agree that this entry is not a hit
-            double t;
-            if (tri_collide(T, o, d, &t)) atomicAdd(&stats[2], 1ull);
-        }
-        leaf_test(T, entry, o, d, best);
-        PH(5);
-    }
-}
-
 // KDTree::collide (kdtree.rs:192-235).  Returns the winning stream entry in out->entry (-1 = miss).
 template <int CULL>
-RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, V3 inv, LeafBest* out,
-                          unsigned long long* stats PH_ARG) {
+RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, LeafBest* out,
+                          unsigned long long* stats) {
     out->entry = -1; out->dist = kF64Max; out->t = 0.0;
+    CNT(1);
+    const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);   // aabb.rs:74, same for every box test of this ray
     V3 point;
     {
         const RRT_GLOBAL DBox* rb = as_global(M.boxes);
         if (!box_collide(ld3g(rb->mn), ld3g(rb->mx), o, d, inv, &point)) return;
     }
+    CNT(2);
     point = point + d * 0.01;
     int32_t leaf = find_point(M, lnodes, 0, point);
     CullRay cr;
-    if (CULL != 0) cr = make_cull_ray(M, o, d);
+    if (CULL != 0) cr = make_cull_ray(M, o, d, inv);
     const RRT_GLOBAL DLeaf* leaves = as_global(M.leaves);
     const RRT_GLOBAL DTri* stream = as_global(M.tris);
     uint32_t visits = 0;
@@ -365,50 +367,70 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, V3 i
             return;
         }
         const RRT_GLOBAL DLeaf* L = leaves + leaf;
-        PH(2);
+        CNT(4);
         const int32_t first = L->first, count = L->count;
-#if RRT_PROBE
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        PH(3);
         LeafBest best;
         best.dist = kF64Max; best.t = 0.0; best.entry = -1;
         const RRT_GLOBAL DTri* tp = stream + first;
-        const int32_t last = count - 1;
         if (CULL == 0) {
             // Software pipeline over the leaf's contiguous triangle stream, unrolled by two so the
             // prefetched triangle lands in the other register set (no copies): while A is tested B
-            // is in flight and vice versa.  The clamped index re-reads the last one instead of branching.
+            // is in flight and vice versa.  The prefetch may run up to two entries past the leaf:
+            // the next leaf's entries, or the two pad entries the host appends to both arrays.
             TriData A = ld_tri(tp);
             for (int32_t k = 0; k < count; k += 2) {
-                const TriData B = ld_tri(tp + (k + 1 < last ? k + 1 : last));
+                const TriData B = ld_tri(tp + k + 1);
                 leaf_test(A, first + k, o, d, &best);
-                A = ld_tri(tp + (k + 2 < last ? k + 2 : last));
+                A = ld_tri(tp + k + 2);
                 if (k + 1 < count) leaf_test(B, first + k + 1, o, d, &best);
             }
         } else {
-            // Same pipeline over the 24-byte cull boxes; the 72-byte f64 triangle is fetched only
-            // for the entries that survive the cull.
+            // Two phases per chunk of up to 32 stream entries.  Cull phase: a branch-free loop over
+            // the 24-byte cull boxes, four per trip with all four loads issued before the first test,
+            // that leaves one keep bit per entry.  Exact phase: the f64 test (72-byte triangle) for the
+            // set bits only, in stream order (ties keep the first, kdtree.rs:207) -- lanes advance by
+            // their own next kept entry, so a wave runs max-over-lanes(kept) exact tests, not one per
+            // entry that any lane kept.  The box loads may run up to three entries past the leaf
+            // (kStreamPad); those bits are masked off.
             const RRT_GLOBAL DBox32* bp = as_global(M.cull) + first;
-            Box32 A = ld_box32(bp);
-            for (int32_t k = 0; k < count; k += 2) {
-                const Box32 B = ld_box32(bp + (k + 1 < last ? k + 1 : last));
-                cull_or_test<CULL>(A, tp + k, first + k, o, d, cr, &best, stats PH_PASS);
-                A = ld_box32(bp + (k + 2 < last ? k + 2 : last));
-                if (k + 1 < count) cull_or_test<CULL>(B, tp + k + 1, first + k + 1, o, d, cr, &best, stats PH_PASS);
+            for (int32_t base = 0; base < count; base += 32) {
+                const int32_t n = count - base < 32 ? count - base : 32;
+                uint32_t keep = 0u;
+                for (int32_t k = 0; k < n; k += 4) {
+                    const RRT_GLOBAL DBox32* q = bp + base + k;
+                    const Box32 b0 = ld_box32(q), b1 = ld_box32(q + 1), b2 = ld_box32(q + 2), b3 = ld_box32(q + 3);
+                    CNT(5);
+                    const uint32_t m = (cull_keep(b0, cr) ? 1u : 0u) | (cull_keep(b1, cr) ? 2u : 0u) |
+                                       (cull_keep(b2, cr) ? 4u : 0u) | (cull_keep(b3, cr) ? 8u : 0u);
+                    keep |= m << k;
+                }
+                const uint32_t valid = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
+                keep &= valid;
+                uint32_t todo = (CULL == 2) ? valid : keep;   // verify mode runs every entry
+                while (todo != 0u) {
+                    CNT(6);
+                    const int32_t j = __ffs((int)todo) - 1;
+                    todo &= todo - 1u;
+                    const int32_t e = base + j;
+                    const TriData T = ld_tri(tp + e);
+                    if (CULL == 2 && ((keep >> j) & 1u) == 0u) {   // the exact test must agree this is no hit
+                        double t;
+                        if (tri_collide(T, o, d, &t)) atomicAdd(&stats[2], 1ull);
+                    }
+                    leaf_test(T, first + e, o, d, &best);
+                }
             }
         }
-        PH(4);
         if (best.entry >= 0) {
             *out = best;
             return;
         }
+        CNT(7);
         const V3 mn = ld3g(L->mn), mx = ld3g(L->mx);
         point = box_exit(mn, mx, point, d, inv) + d * 0.001;
         const int32_t nb = L->rope[get_plane(point, mn, mx)];
         if (nb < 0) return;
         leaf = find_point(M, lnodes, nb, point);
-        PH(6);
     }
 }
 
@@ -450,8 +472,7 @@ struct Closest {
 // The entity loop of RayTracer::cast (tracer.rs:178-190)
 template <int CULL>
 RRT_DEV void closest_hit(const DScene& sc, const DNodeI* lnodes, V3 o, V3 d, int32_t medium, Closest* best,
-                         unsigned long long* stats PH_ARG) {
-    const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);   // aabb.rs:74, same for every box test of this ray
+                         unsigned long long* stats) {
     best->dist = kF64Max; best->t = 0.0; best->ent = -1; best->entry = -1;
     for (int32_t e = 0; e < sc.n_ents; ++e) {
         const DEntity ent = sc.ents[e];
@@ -467,9 +488,7 @@ RRT_DEV void closest_hit(const DScene& sc, const DNodeI* lnodes, V3 o, V3 d, int
         } else {
             const DMesh M = sc.meshes[ent.index];
             LeafBest h;
-            PH(1);
-            mesh_collide<CULL>(M, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, inv, &h, stats PH_PASS);
-            PH(2);
+            mesh_collide<CULL>(M, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, &h, stats);
             // same |pos - origin|^2 as the leaf-level metric (kdtree.rs:206 == tracer.rs:184)
             if (h.entry >= 0 && h.dist < best->dist) {
                 best->dist = h.dist; best->t = h.t; best->ent = e; best->entry = h.entry;
@@ -501,6 +520,17 @@ RRT_DEV void finish_hit(const DScene& sc, V3 o, V3 d, const Closest& c, Hit* h) 
     }
 }
 
+// texel / 255.0 (cubemap.rs:70-74) for the 256 possible texel values, divided at compile time
+// (IEEE round-to-nearest, the same quotient the device's f64 division gives): three table loads
+// replace three ~30-instruction f64 divisions per sky lookup.
+struct By255 {
+    double v[256];
+    constexpr By255() : v{} {
+        for (int i = 0; i < 256; ++i) v[i] = (double)i / 255.0;
+    }
+};
+__device__ const By255 kBy255{};
+
 // cubemap() + CubemapBehavior::compute (cubemap.rs:84-164, 56-77)
 RRT_DEV V3 sky_color(const DScene& sc, V3 dir) {
     const double x = dir.x, y = dir.y, z = dir.z;
@@ -521,7 +551,11 @@ RRT_DEV V3 sky_color(const DScene& sc, V3 dir) {
     if (px >= w) px = w - 1;
     if (py >= hgt) py = hgt - 1;
     const uint8_t* p = sc.sky[idx] + ((size_t)py * w + px) * 3;
+#ifndef RRT_NO_LUT
+    return mk(kBy255.v[p[0]], kBy255.v[p[1]], kBy255.v[p[2]]);
+#else
     return mk((double)p[0] / 255.0, (double)p[1] / 255.0, (double)p[2] / 255.0);
+#endif
 }
 
 // Direct terms of a hit (tracer.rs:194-202 with lambert.rs:22-45, phong.rs:25-47):
@@ -650,13 +684,8 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
     V3 ro = mk(0., 0., 0.), rd = mk(0., 0., 0.);
     if (active) {
         Closest c;
-#if RRT_PROBE
-        Phases ph;
-        for (int q_ = 0; q_ < 8; ++q_) ph.acc[q_] = 0;
-        ph.t = __builtin_amdgcn_s_memtime();
-#endif
-        closest_hit<CULL>(sc, lnodes, o, d, medium, &c, wk.stats PH_PASS);
-        PH(1);
+        CNT(0);
+        closest_hit<CULL>(sc, lnodes, o, d, medium, &c, wk.stats);
         Hit h;
         finish_hit(sc, o, d, c, &h);
         const int32_t ent = c.ent;
@@ -668,6 +697,7 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
         if (h.hit) {
             const DMaterial m = sc.mats[h.mat];
             V3 A, Pm;
+            CNT(9);
             shade_direct(sc, m, d, h.normal, &A, &Pm);
             cont = !(bounce > fr.max_bounce) && !(fr.prune && m.mixR == 0.0);
             if (cont) {
@@ -681,9 +711,11 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
                 col = A + Pm;   // Reflection returned None (reflection.rs:26-28) or was pruned
             }
         } else {
+            CNT(8);
             col = sky_color(sc, d);
         }
         if (!cont) {
+            CNT(10);
             // fold the enclosing casts: final = (A + R*mixR) + Pm  (tracer.rs:194-202)
             for (uint32_t k = bounce; k-- > 0;) {
                 const size_t r = (size_t)k * 3 * P + path;
@@ -694,18 +726,6 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
             }
             wk.samp[path] = col.x; wk.samp[path + P] = col.y; wk.samp[path + 2 * P] = col.z;
         }
-#if RRT_PROBE
-        PH(7);
-        for (int q_ = 0; q_ < 8; ++q_) atomicMax(&g_phase[8 + q_], ph.acc[q_]);      // (debug) keeps them live
-        for (int q_ = 0; q_ < 8; ++q_) {
-            unsigned long long m_ = ph.acc[q_];
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned long long o_ = __shfl_xor(m_, off, 64);
-                m_ = o_ > m_ ? o_ : m_;
-            }
-            if (__lane_id() == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&g_phase[q_], m_);
-        }
-#endif
     }
     const uint32_t slot = queue_slot(&wk.q_count[bounce + 1], cont);
     if (cont) {
@@ -732,7 +752,7 @@ RRT_DEV const DNodeI* stage_nodes(const DScene& sc, unsigned char* smem) {
 // Persistent blocks: block b takes path tiles b, b + grid, ... (neighbouring tiles, which cost
 // about the same, go to different blocks), so the LDS staging is paid once per block.
 template <int CULL>
-__global__ __launch_bounds__(256, 4) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
+__global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DNodeI* lnodes = stage_nodes(sc, smem);
     const uint32_t n_chunks = (uint32_t)(((uint64_t)fr.ns * fr.npx_local) >> 8);   // 256 paths per chunk, exact
@@ -749,7 +769,7 @@ __global__ __launch_bounds__(256, 4) void k_wave_primary(DScene sc, DWork wk, DF
 }
 
 template <int CULL>
-__global__ __launch_bounds__(256, 4) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
+__global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = wk.q_count[bounce];
     const uint32_t stride = gridDim.x * 256u;
@@ -842,14 +862,11 @@ __global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* ray
                                                     unsigned long long* stats) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-#if RRT_PROBE
-    Phases ph_dummy{};
-#endif
     const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
     Closest c;
-    if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, -1, &c, stats PH_DUMMY);
-    else if (sc.cull_mode == 1) closest_hit<1>(sc, nullptr, o, d, -1, &c, stats PH_DUMMY);
-    else closest_hit<2>(sc, nullptr, o, d, -1, &c, stats PH_DUMMY);
+    if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, -1, &c, stats);
+    else if (sc.cull_mode == 1) closest_hit<1>(sc, nullptr, o, d, -1, &c, stats);
+    else closest_hit<2>(sc, nullptr, o, d, -1, &c, stats);
     Hit h;
     finish_hit(sc, o, d, c, &h);
     const int32_t e = c.ent;
@@ -865,9 +882,6 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
                                                    uint32_t prune, double* color, unsigned long long* stats) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-#if RRT_PROBE
-    Phases ph_dummy{};
-#endif
     V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
     V3 sA[kMaxLevels], sP[kMaxLevels];
     double sR[kMaxLevels];
@@ -877,8 +891,8 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
     V3 col;
     for (;;) {
         Closest c;
-        if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, medium, &c, stats PH_DUMMY);
-        else closest_hit<2>(sc, nullptr, o, d, medium, &c, stats PH_DUMMY);
+        if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, medium, &c, stats);
+        else closest_hit<2>(sc, nullptr, o, d, medium, &c, stats);
         Hit h;
         finish_hit(sc, o, d, c, &h);
         if (!h.hit) { col = sky_color(sc, d); break; }
@@ -961,10 +975,10 @@ void launch_selftest(int op, const double* a, const double* b, int64_t n, double
     hipLaunchKernelGGL(k_selftest, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, n,
                        out);
 }
-void debug_phases(unsigned long long out[16]) {
+void debug_phases(unsigned long long out[32]) {
 #if RRT_PROBE
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), 16 * sizeof(unsigned long long));
-    unsigned long long z[16] = {};
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), 32 * sizeof(unsigned long long));
+    unsigned long long z[32] = {};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z));
 #else
     for (int i = 0; i < 16; ++i) out[i] = 0;

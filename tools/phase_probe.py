@@ -1,23 +1,28 @@
-#!/usr/bin/env python3
-"""Per-phase wave-cycle shares of the trace kernels (needs the -DRRT_PROBE=1 library:
-RRT_LIB=rustraytracer_amd/librrt_probe.so python tools/phase_probe.py)."""
-import ctypes as C, os, sys
+"""Wave-level event counts of one cfg2 frame (diagnostic build: make -C rustraytracer_amd/csrc
+probe; run with RRT_LIB=rustraytracer_amd/librrt_probe.so).  For each site: waves that reached it,
+active lanes, and the per-ray averages -- multiply by the block's static instruction count in
+rrt_kernels.s for the issue budget."""
+import ctypes
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from rustraytracer_amd import host as H, scenes, binding as B
-names = ["-", "entity loop excl. mesh (spheres, ray setup)", "mesh: setup/root box/find_point + leaf pointer",
-         "leaf header load (first,count)", "cull loop (boxes, loop overhead)", "exact f64 triangle tests (load+test)",
-         "leaf advance (box load, exit, rope, find_point)", "finish_hit + shading + sky + records + stores"]
-w = scenes.cfg2_scene(H.World(device=0), H.loaders); w.commit()
-st = H.make_settings(1920, 1080, spp=16)
-buf = torch.empty((1080, 1920, 3), dtype=torch.uint8, device="cuda")
-out = (C.c_ulonglong * 16)()
-w.render_device(st, buf.data_ptr()); torch.cuda.synchronize()
+from rustraytracer_amd import binding as B, host as H, scenes  # noqa: E402
+
+NAMES = ["cast (process_ray)", "mesh_collide entered", "root box passed", "descent steps (LDS)",
+         "leaf visits", "cull tests", "exact tests", "leaf advances", "sky lookups", "shade_direct",
+         "path folds"]
+w = scenes.cfg2_scene(H.World(device=0), H.loaders)
+spp = int(os.environ.get("SPP", "4"))
+out = (ctypes.c_ulonglong * 32)()
+w.render(1920, 1080, spp=spp, seed=1, want=("rgb",))
+B.lib.rrt_debug_phases(out)          # read + clear (warm-up frame)
+r = w.render(1920, 1080, spp=spp, seed=1, want=("rgb",))
 B.lib.rrt_debug_phases(out)
-w.render_device(st, buf.data_ptr()); torch.cuda.synchronize()
-B.lib.rrt_debug_phases(out)
-tot = sum(out[:8])
-s = w.stats()
-print("gpu %.3f ms primary %.3f bounce %.3f (probe build; read shares, not lengths)" % (s["gpu_ms"], s["primary_kernel_ms"], s["bounce_kernel_ms"]))
-for i in range(1, 8):
-    print("  %-62s %6.2f %%   (lane max %d cyc)" % (names[i], 100.0 * out[i] / tot, out[8 + i]))
+rays = r["stats"]["rays_traced"]
+print("rays %d  (wave-rays if fully packed: %d)" % (rays, rays // 64))
+print("%-24s %14s %14s %10s %12s %12s" % ("site", "waves", "lanes", "lanes/wave", "waves/wray", "lanes/ray"))
+wr = max(out[0], 1)
+for i, n in enumerate(NAMES):
+    wv, ln = out[2 * i], out[2 * i + 1]
+    print("%-24s %14d %14d %10.1f %12.2f %12.2f" % (n, wv, ln, ln / max(wv, 1), wv / wr, ln / max(out[1], 1)))
