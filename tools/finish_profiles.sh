@@ -1,0 +1,20 @@
+#!/bin/bash
+# Copies what tools/collect_all.sh produced (merged back under gpurun_out/) into profiles/.
+set -e
+TAG=${1:-r01}
+cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
+cp gpurun_out/${TAG}_kernel_stats.csv profiles/${TAG}_kernel_stats.csv
+cp gpurun_out/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
+cp gpurun_out/${TAG}_sq_summary.txt profiles/${TAG}_sq_summary.txt
+for C in FETCH_SIZE WRITE_SIZE; do
+  f=$(find gpurun_out/pmc_$TAG/$C -name "*counter_collection.csv" | head -1)
+  python3 - "$f" profiles/${TAG}_pmc_$C.csv <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_" in r["Kernel_Name"]]
+keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value"]
+keep = [k for k in keep if rows and k in rows[0]]
+w = csv.DictWriter(open(sys.argv[2], "w"), keep); w.writeheader()
+for r in rows: w.writerow({k: r[k] for k in keep})
+PY
+done
+ls -la profiles

@@ -3,10 +3,14 @@
 profiles/pmc_traffic.json: HBM bytes per launch for each hot kernel.
 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and
-WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide
-coalesced streaming reads.  This path's reads are narrow, divergent (8-24 B
-per lane) -- an uncalibrated width -- so both the raw and the doubled read
-figure are kept and `hbm_bytes_per_launch` uses the raw one (lower bound)."""
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a
+coalesced streaming read, WRITE_SIZE reads exactly.  The guide calibrates that
+on 16 B/lane accesses and calls other widths uncalibrated; this path moves
+8 B/lane, so it is calibrated here on k_accumulate, whose traffic is known
+exactly (it reads 24 B per path sample and writes 24 B per pixel, nothing
+else): the `calibration` entry holds counter/known ratios (measured: reads
+0.50, writes 1.00, i.e. the guide's factors hold at 8 B/lane).  Reads are
+therefore doubled: `hbm_bytes_per_launch` = 2 x FETCH_SIZE + WRITE_SIZE."""
 import csv
 import glob
 import json
@@ -40,10 +44,17 @@ def main():
         rd = fs / n * 1024.0
         wr = ws / max(nw, 1) * 1024.0
         out[short] = {"launches": n, "fetch_bytes_per_launch_raw": rd, "fetch_bytes_per_launch_x2": 2 * rd,
-                      "write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+                      "write_bytes_per_launch": wr, "hbm_bytes_per_launch": 2 * rd + wr,
                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, "
-                                "bench.py --steps 2 (tools/collect_pmc.sh); read side raw (narrow divergent loads, "
-                                "x2 correction for wide streams not applied)"}
+                                "bench.py --steps 2 (tools/collect_pmc.sh); gfx950 correction: reads x2 "
+                                "(calibrated on k_accumulate's known byte counts, see `calibration`)"}
+    if "k_accumulate" in out:
+        # cfg2 bench frame: 1920x1080 pixels padded to 32x8 tiles, 16 spp in one batch
+        npx = ((1920 + 31) // 32) * ((1080 + 7) // 8) * 256
+        a = out["k_accumulate"]
+        out["calibration"] = {"kernel": "k_accumulate", "known_read_bytes": npx * 16 * 24, "known_write_bytes": npx * 24,
+                              "fetch_raw_over_known": a["fetch_bytes_per_launch_raw"] / (npx * 16 * 24),
+                              "write_over_known": a["write_bytes_per_launch"] / (npx * 24)}
     json.dump(out, sys.stdout, indent=1)
     print()
 
