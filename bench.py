@@ -35,6 +35,16 @@ import torch.distributed as dist  # noqa: E402
 
 W, H, SPP = 1920, 1080, 16
 
+# --config: the other BASELINE.json configs (parity-test cases; measured for the table in DESIGN.md,
+# not the contract's bench line, which is cfg2).  name -> (scene function, W, H, spp, max_bounce, what)
+CONFIGS = {
+    "cfg1": ("cfg1_scene", 640, 480, 1, 2, "configs[0]: cube.obj + 3 spheres, sky cubemap, 640x480, 1 spp"),
+    "cfg2": ("cfg2_scene", W, H, SPP, 2, "configs[1]"),
+    "cfg3": ("cfg3_scene", 1920, 1080, 1, 8, "configs[2]: reflect/refract glass-sphere scene, depth 8, 1920x1080, 1 spp (extension lobes)"),
+    "cfg4": ("cfg4_scene", 3840, 2160, 256, 2, "configs[3]: ufo_fix.obj with stochastic diffuse bounces, 3840x2160, 256 spp (extension lobes)"),
+    "cfg5": ("cfg5_scene", 1920, 1080, 64, 2, "configs[4]: synthetic 2M-triangle height field, diffuse bounces, 1920x1080, 64 spp (extension lobes)"),
+}
+
 # Algorithmic work per ray for the roofline (DESIGN.md "Measurement"): sizes of the
 # device layout in csrc/rrt_device.h and flop counts of SURVEY §8(d).
 S_NODE, S_LEAF, S_TRI, S_HITN = 16, 88, 76, 24     # bytes: interior step / leaf header / triangle test / winner's normal
@@ -94,6 +104,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--batch-spp", type=int, default=0, help="samples per pixel per wavefront batch (0 = from the work budget)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",
+                    help="BASELINE.json config to run (default cfg2 = the contract's workload; the others "
+                         "print the same line without roofline/cpu_baseline)")
     ap.add_argument("--budget-gib", type=float, default=0.0, help="work-buffer budget in GiB (0 = library default)")
     args = ap.parse_args()
 
@@ -109,12 +122,14 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from rustraytracer_amd import host as Hst, scenes
-    scene = scenes.cfg2_scene(Hst.World(device=local_rank), Hst.loaders)
+    global W, H, SPP
+    scene_fn, W, H, SPP, max_bounce, what = CONFIGS[args.config]
+    scene = getattr(scenes, scene_fn)(Hst.World(device=local_rank), Hst.loaders)
     if args.budget_gib > 0:
         scene.set_work_budget(int(args.budget_gib * (1 << 30)))
     scene.commit()                                   # scene resident in HBM before timing
     spp = SPP * world if args.scaling == "weak" else SPP
-    st = Hst.make_settings(W, H, spp=spp, max_bounce=2, seed=0, prune_zero_mix=args.prune,
+    st = Hst.make_settings(W, H, spp=spp, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune,
                            tile_rank=rank, tile_world=world, batch_spp=args.batch_spp)
     from rustraytracer_amd import distributed as D
     frame = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
@@ -165,16 +180,21 @@ def main():
             "data": "synthetic camera rays over the reference's own assets (obj/ufo_fix.obj, cubemaps/blue_sunset)",
             "config": {"workload": "BASELINE configs[1]: main.rs world (ufo_fix.obj rope kd-tree, 1705 tris, + 2 spheres), "
                                    "blue_sunset cubemap, %dx%d, %d spp%s, max_bounce 2, reference ray semantics (prune_zero_mix=%d)"
-                                   % (W, H, spp, " (16 per GPU)" if world > 1 and args.scaling == "weak" else "", args.prune),
+                                   % (W, H, spp, " (16 per GPU)" if world > 1 and args.scaling == "weak" else "", args.prune)
+                       if args.config == "cfg2" else "BASELINE %s; %d spp in total, max_bounce %d" % (what, spp, max_bounce),
                        "rays_per_step": rays_step, "samples_per_step": paths_step,
                        "msamples_per_s": paths_step * args.steps / dt / 1e6,
                        "parallelism": "tiles%d" % world, "traversal_overflow": overflow},
         }
         cpu_c = prim_c = None
-        if world == 1 and not args.no_cpu_baseline:
+        if args.config != "cfg2":
+            line["metric"] = "Mrays/s (node) %s" % args.config
+            line["config"]["n_batches"] = stats["n_batches"]
+            line["config"]["level_rays"] = stats["level_rays"]
+        if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             nthreads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
             line["cpu_baseline"], cpu_c, prim_c, n_prim = cpu_leg(nthreads)
-        if world == 1:
+        if world == 1 and args.config == "cfg2":
             # Dominant kernel = k_wave_primary (one launch per wavefront batch).  Its roofline is priced as
             # DESIGN.md "Measurement" states: the scene of this config (~0.4 MB of nodes/triangles) is
             # cache-resident, so the bytes that MUST cross HBM per primary ray are its outputs only:
