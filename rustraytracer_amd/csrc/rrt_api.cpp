@@ -62,7 +62,7 @@ struct HostMesh {
     rrt::KdTreeFlat tree;
     int material = 0;
     // device copies
-    DevBuf d_nodes, d_boxes, d_leaves, d_refs, d_tris, d_normals, d_cull;
+    DevBuf d_nodes, d_boxes, d_leaves, d_refs, d_tris, d_normals, d_cull, d_grp;
 };
 
 struct SkyFace {
@@ -161,12 +161,24 @@ int commit(rrt_scene* s) {
         }
         HIP_TRY(m.d_nodes.upload(nodes.data(), nodes.size() * sizeof(rrt::DNodeI)));
         HIP_TRY(m.d_boxes.upload(boxes.data(), boxes.size() * sizeof(rrt::DBox)));
+        // Leaf-ordered stream, every leaf's run aligned to kGroup entries and padded to a multiple of
+        // it (pad = copy of the run's last entry, never tested: the kernels mask by the leaf's count).
+        constexpr int32_t G = rrt::kGroup;
+        std::vector<int32_t> refs;
+        refs.reserve(T.leaf_refs.size() + (size_t)G * leaves.size());
+        for (rrt::DLeaf& L : leaves) {
+            const int32_t src = L.first;
+            L.first = (int32_t)refs.size();
+            for (int32_t k = 0; k < L.count; ++k) refs.push_back(T.leaf_refs[(size_t)src + k]);
+            while (refs.size() % G) refs.push_back(refs.back());
+        }
+        if (refs.size() > 0x7fffffffull - 64) return fail(RRT_E_INVALID, "mesh too large (triangle stream index exceeds 31 bits)");
         HIP_TRY(m.d_leaves.upload(leaves.data(), leaves.size() * sizeof(rrt::DLeaf)));
-        HIP_TRY(m.d_refs.upload(T.leaf_refs.data(), T.leaf_refs.size() * sizeof(int32_t)));
-        std::vector<rrt::DTri> stream(T.leaf_refs.size());
-        for (size_t j = 0; j < stream.size(); ++j) stream[j] = m.tris[(size_t)T.leaf_refs[j]];
+        HIP_TRY(m.d_refs.upload(refs.data(), refs.size() * sizeof(int32_t)));
+        std::vector<rrt::DTri> stream(refs.size());
+        for (size_t j = 0; j < stream.size(); ++j) stream[j] = m.tris[(size_t)refs[j]];
         {
-            // the leaf loop prefetches up to kStreamPad entries past a leaf: keep them readable
+            // the un-culled leaf loop prefetches up to kStreamPad entries past a leaf: keep them readable
             std::vector<rrt::DTri> padded(stream);
             padded.resize(stream.size() + rrt::kStreamPad, stream.empty() ? rrt::DTri{} : stream.back());
             HIP_TRY(m.d_tris.upload(padded.data(), padded.size() * sizeof(rrt::DTri)));
@@ -190,8 +202,21 @@ int commit(rrt_scene* s) {
             }
             edge_max = std::fmax(edge_max, std::sqrt(std::fmax(l1, l2)));
         }
-        cull.resize(stream.size() + rrt::kStreamPad, cull.empty() ? rrt::DBox32{} : cull.back());
+        // one box per group of kGroup consecutive entries: the union of its entries' boxes
+        std::vector<rrt::DBox32> grp(stream.size() / G + rrt::kStreamPad);
+        for (size_t g = 0; g < stream.size() / G; ++g) {
+            rrt::DBox32 u = cull[g * G];
+            for (int32_t k = 1; k < G; ++k)
+                for (int a = 0; a < 3; ++a) {
+                    u.v[2 * a] = std::fmin(u.v[2 * a], cull[g * G + k].v[2 * a]);
+                    u.v[2 * a + 1] = std::fmax(u.v[2 * a + 1], cull[g * G + k].v[2 * a + 1]);
+                }
+            grp[g] = u;
+        }
+        for (size_t g = stream.size() / G; g < grp.size(); ++g) grp[g] = stream.empty() ? rrt::DBox32{} : grp[stream.size() / G - 1];
         HIP_TRY(m.d_cull.upload(cull.data(), cull.size() * sizeof(rrt::DBox32)));
+        HIP_TRY(m.d_grp.upload(grp.data(), grp.size() * sizeof(rrt::DBox32)));
+        dm[i].grp = m.d_grp.as<rrt::DBox32>();
         dm[i].cull = m.d_cull.as<rrt::DBox32>();
         dm[i].edge_max = edge_max * (1.0 + 1e-9);
         {

@@ -36,7 +36,7 @@ struct DLeaf {
     double mn[3];
     double mx[3];
     int32_t rope[6];   // node index or -1; 0..2 = -x,-y,-z faces, 3..5 = +x,+y,+z
-    int32_t first;     // first entry in the triangle stream
+    int32_t first;     // first entry in the triangle stream (multiple of kGroup)
     int32_t count;
 };
 static_assert(sizeof(DLeaf) == 80, "DLeaf layout");
@@ -63,7 +63,8 @@ struct DMesh {
                                 // leaf, so a leaf's triangles are contiguous and the next one can be prefetched)
     const double* normals;  // 3 per triangle (indexed by triangle id)
     const DBox32* cull;     // per stream entry, see "conservative cull" in rrt_kernels.hip
-                            // (tris and cull carry kStreamPad extra entries for the prefetch to run into)
+    const DBox32* grp;      // per group of kGroup consecutive stream entries: union of their cull boxes
+                            // (tris and grp carry kStreamPad extra entries for the loops to run into)
     int32_t material;
     int32_t n_nodes;
     // constants of the conservative cull (host-computed, f64)
@@ -117,7 +118,8 @@ struct DScene {
     int32_t pad0;
 };
 
-constexpr int32_t kStreamPad = 4;        // readable entries past the end of DMesh::tris / DMesh::cull
+constexpr int32_t kGroup = 4;            // a leaf's run in the stream starts at a multiple of kGroup and is padded to one
+constexpr int32_t kStreamPad = 4;        // readable entries past the end of DMesh::tris / DMesh::grp
 constexpr int32_t kMaxLdsNodes = 3072;   // 48 KB of LDS per 256-thread block at most
 
 // Ray queue, SoA.  cap entries each.

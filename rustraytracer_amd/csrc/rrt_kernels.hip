@@ -385,24 +385,41 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, Leaf
                 if (k + 1 < count) leaf_test(B, first + k + 1, o, d, &best);
             }
         } else {
-            // Two phases per chunk of up to 32 stream entries.  Cull phase: a branch-free loop over
-            // the 24-byte cull boxes, four per trip with all four loads issued before the first test,
-            // that leaves one keep bit per entry.  Exact phase: the f64 test (72-byte triangle) for the
-            // set bits only, in stream order (ties keep the first, kdtree.rs:207) -- lanes advance by
-            // their own next kept entry, so a wave runs max-over-lanes(kept) exact tests, not one per
-            // entry that any lane kept.  The box loads may run up to three entries past the leaf
-            // (kStreamPad); those bits are masked off.
+            // Three phases per chunk of up to 32 stream entries (8 groups of kGroup = 4).
+            //  1. group cull: the union boxes of the chunk's groups, four loaded per trip before the
+            //     first test, branch-free, one keep bit per group;
+            //  2. entry cull: for each kept group (lanes advance by their own next kept group) its
+            //     four 24-byte entry boxes, one keep bit per entry;
+            //  3. exact: the f64 test (72-byte triangle) for the kept entries, in stream order (ties
+            //     keep the first, kdtree.rs:207), again by each lane's own next kept entry -- a wave
+            //     runs max-over-lanes(kept) tests, not one per entry that any lane kept.
+            // Reads past the leaf stay inside the padded arrays; those bits are masked off.
+            static_assert(kGroup == 4, "the leaf loop is written for groups of four");
             const RRT_GLOBAL DBox32* bp = as_global(M.cull) + first;
+            const RRT_GLOBAL DBox32* gp = as_global(M.grp) + (first >> 2);
             for (int32_t base = 0; base < count; base += 32) {
                 const int32_t n = count - base < 32 ? count - base : 32;
-                uint32_t keep = 0u;
-                for (int32_t k = 0; k < n; k += 4) {
-                    const RRT_GLOBAL DBox32* q = bp + base + k;
+                const int32_t ng = (n + 3) >> 2;
+                uint32_t gkeep = 0u;
+                for (int32_t g = 0; g < ng; g += 4) {
+                    const RRT_GLOBAL DBox32* q = gp + (base >> 2) + g;
                     const Box32 b0 = ld_box32(q), b1 = ld_box32(q + 1), b2 = ld_box32(q + 2), b3 = ld_box32(q + 3);
                     CNT(5);
                     const uint32_t m = (cull_keep(b0, cr) ? 1u : 0u) | (cull_keep(b1, cr) ? 2u : 0u) |
                                        (cull_keep(b2, cr) ? 4u : 0u) | (cull_keep(b3, cr) ? 8u : 0u);
-                    keep |= m << k;
+                    gkeep |= m << g;
+                }
+                gkeep &= (1u << ng) - 1u;
+                uint32_t keep = 0u;
+                while (gkeep != 0u) {
+                    CNT(11);
+                    const int32_t g = __ffs((int)gkeep) - 1;
+                    gkeep &= gkeep - 1u;
+                    const RRT_GLOBAL DBox32* q = bp + base + 4 * g;
+                    const Box32 b0 = ld_box32(q), b1 = ld_box32(q + 1), b2 = ld_box32(q + 2), b3 = ld_box32(q + 3);
+                    const uint32_t m = (cull_keep(b0, cr) ? 1u : 0u) | (cull_keep(b1, cr) ? 2u : 0u) |
+                                       (cull_keep(b2, cr) ? 4u : 0u) | (cull_keep(b3, cr) ? 8u : 0u);
+                    keep |= m << (4 * g);
                 }
                 const uint32_t valid = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
                 keep &= valid;

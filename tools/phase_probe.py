@@ -10,9 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rustraytracer_amd import binding as B, host as H, scenes  # noqa: E402
 
 NAMES = ["cast (process_ray)", "mesh_collide entered", "root box passed", "descent steps (LDS)",
-         "leaf visits", "cull tests", "exact tests", "leaf advances", "sky lookups", "shade_direct",
-         "path folds"]
-w = scenes.cfg2_scene(H.World(device=0), H.loaders)
+         "leaf visits", "group-cull trips (4 groups)", "exact tests", "leaf advances", "sky lookups", "shade_direct",
+         "path folds", "entry-cull trips (1 group)"]
+cfg = os.environ.get("CFG", "cfg2")
+w = getattr(scenes, cfg + "_scene")(H.World(device=0), H.loaders)
 spp = int(os.environ.get("SPP", "4"))
 out = (ctypes.c_ulonglong * 32)()
 w.render(1920, 1080, spp=spp, seed=1, want=("rgb",))
