@@ -167,6 +167,21 @@ def main():
     prim_ms, prim_n = stats["primary_kernel_ms"], stats["primary_kernel_launches"]
     bnc_ms, bnc_n = stats["bounce_kernel_ms"], stats["bounce_kernel_launches"]
 
+    host_ms = None
+    if world == 1:
+        # PCIe-inclusive variant (never `value`): rrt_render into host memory = the same frame + one D2H copy
+        import numpy as np
+        import ctypes as C
+        from rustraytracer_amd import binding as B
+        rgb = np.zeros((H, W, 3), np.uint8)
+        cam = Hst.default_camera()
+        n_host = max(2, min(args.steps, 5))
+        for it in range(n_host + 1):
+            if it == 1:
+                th = time.perf_counter()
+            B.check(B.lib.rrt_render(scene.h, C.byref(cam), C.byref(st), rgb.ctypes.data_as(C.c_void_p), None, None, None))
+        host_ms = (time.perf_counter() - th) / n_host * 1e3
+
     dt = D.max_over_ranks(dt, dev)
     rays_step, paths_step, overflow = D.sum_over_ranks(
         [stats["rays_traced"], stats["paths"], stats["traversal_overflow"]], dev)
@@ -186,6 +201,8 @@ def main():
                        "msamples_per_s": paths_step * args.steps / dt / 1e6,
                        "parallelism": "tiles%d" % world, "traversal_overflow": overflow},
         }
+        if host_ms is not None:
+            line["config"]["host_buffer_ms_per_step"] = host_ms      # rrt_render: + D2H of the RGB8 frame, blocking
         cpu_c = prim_c = None
         if args.config != "cfg2":
             line["metric"] = "Mrays/s (node) %s" % args.config

@@ -238,6 +238,7 @@ RRT_DEV int32_t find_point(const DMesh& M, const DNodeI* lnodes, int32_t at, V3 
     double split = gn[at].split;
     int32_t axis = gn[at].axis, right = gn[at].right;
     while (axis >= 0) {
+        CNT(3);
         at = (comp(p, axis) >= split) ? right : at + 1;
         split = gn[at].split; axis = gn[at].axis; right = gn[at].right;
     }

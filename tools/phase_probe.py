@@ -9,7 +9,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rustraytracer_amd import binding as B, host as H, scenes  # noqa: E402
 
-NAMES = ["cast (process_ray)", "mesh_collide entered", "root box passed", "descent steps (LDS)",
+NAMES = ["cast (process_ray)", "mesh_collide entered", "root box passed", "descent steps",
          "leaf visits", "group-cull trips (4 groups)", "exact tests", "leaf advances", "sky lookups", "shade_direct",
          "path folds", "entry-cull trips (1 group)"]
 cfg = os.environ.get("CFG", "cfg2")
