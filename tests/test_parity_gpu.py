@@ -209,6 +209,79 @@ def test_conservative_cull_is_exact(H, O, scenes):
             assert big["stats"]["cull_violations"] == 0
 
 
+def test_adversarial_geometry(H, O, scenes):
+    """Meshes and rays chosen to sit on the comparisons: rays through exact vertices and along
+    shared edges (equal-distance ties: the first triangle in leaf order must win), origins on kd
+    split planes and on box faces, directions with +0.0 / -0.0 components, a one-triangle mesh,
+    a mesh of identical triangles (all sort keys tie), zero-area triangles (|a| < 1e-7 rejects), and
+    the same mesh 1e5 units away (the cull's pad must scale).  Cull mode 2: zero violations."""
+    rng = np.random.default_rng(33)
+
+    def grid_mesh(n, origin, scale):
+        # n x n quads, z zig-zags by a quarter so the root box is not flat (a flat box rejects every
+        # ray: aabb.rs:95 nudges the hit point by +0.001); coordinates exactly representable
+        z = lambda i, j: 0.5 * ((i + j) & 1)
+        v = []
+        for j in range(n):
+            for i in range(n):
+                p00, p10 = (i, j, z(i, j)), (i + 1, j, z(i + 1, j))
+                p01, p11 = (i, j + 1, z(i, j + 1)), (i + 1, j + 1, z(i + 1, j + 1))
+                v.append([p00, p10, p11]); v.append([p00, p11, p01])
+        v = np.array(v, np.float64) * scale + np.array(origin)
+        nrm = np.tile(np.array([0.0, 0.0, -1.0]), (len(v), 1))
+        return np.ascontiguousarray(v), np.ascontiguousarray(nrm)
+
+    def build(b, L, shift):
+        scenes.empty_world(b, L, "sky")
+        m = b.add_material((0.5, 0.4, 0.3), 1.0, 0.8, 0.3, 0.2, 20)
+        v, n = grid_mesh(12, (-3.0 + shift, -3.0, 20.0), 0.5)
+        b.add_mesh(v, n, m)                                           # entity 0: grid with shared vertices/edges
+        one = np.array([[[-8.0 + shift, -1.0, 15.0], [-6.0 + shift, -1.0, 15.0], [-7.0 + shift, 1.0, 16.0]]])
+        b.add_mesh(one, np.array([[0.0, 0.0, -1.0]]), m)              # entity 1: a single triangle
+        same = np.repeat(one + (14.0, 0.0, 0.0), 40, axis=0)
+        b.add_mesh(np.ascontiguousarray(same), np.tile([0.0, 0.0, -1.0], (40, 1)), m)   # entity 2: 40 identical
+        deg = grid_mesh(3, (-1.0 + shift, 5.0, 18.0), 1.0)[0]
+        deg[::2, 2] = deg[::2, 0]                                     # collapse every other triangle to a point/line
+        deg[::2, 1] = deg[::2, 0]
+        b.add_mesh(np.ascontiguousarray(deg), np.tile([0.0, 0.0, -1.0], (len(deg), 1)), m)  # entity 3
+        return b
+
+    for shift in (0.0, 1.0e5):
+        c = build(O.OracleScene(), O, shift)
+        # rays from a few eyes through every grid vertex, edge midpoint and cell centre
+        ks = np.arange(0, 12.5, 0.25)
+        gx, gy = np.meshgrid(-3.0 + shift + 0.5 * ks, -3.0 + 0.5 * ks)
+        tg = np.stack([gx.ravel(), gy.ravel(), np.full(gx.size, 20.0)], axis=1)
+        rays = []
+        for eye in ((shift, 0.0, 0.0), (shift + 0.5, 0.25, 3.0), (shift - 2.0, 1.0, 19.0), (shift, 0.0, 25.0)):
+            d = tg - np.array(eye)
+            d = d * (1.0 / np.sqrt((d[:, 0] ** 2 + d[:, 1] ** 2) + d[:, 2] ** 2))[:, None]
+            rays.append(np.concatenate([np.tile(eye, (len(tg), 1)), d], axis=1))
+        # axis-parallel rays (+0.0 and -0.0 components) from origins on vertices, split planes and box faces
+        for sign in (1.0, -1.0):
+            o = tg.copy(); o[:, 2] = 20.0 - sign * rng.choice([0.0, 0.5, 3.0, 20.0], len(tg))
+            for z in (0.0, -0.0):
+                d = np.tile([z, z, sign], (len(tg), 1))
+                rays.append(np.concatenate([o, d], axis=1))
+        # in-plane rays along the grid's edges (parallel to the triangles: a == 0)
+        o = tg.copy(); o[:, 0] = -4.0 + shift
+        rays.append(np.concatenate([o, np.tile([1.0, 0.0, 0.0], (len(tg), 1))], axis=1))
+        rays.append(_random_rays(rng, 20000, target=(shift, 0.0, 18.0), spread=8.0) + np.array([shift, 0, 0, 0, 0, 0]) * 0)
+        rays = np.ascontiguousarray(np.concatenate(rays))
+        want = c.trace_rays(rays)
+        assert (want["ent"] >= 0).sum() > 5000
+        for mode in (1, 2, 0):
+            g = build(H.World(device=0), H.loaders, shift)
+            g.set_cull_mode(mode)
+            got = g.trace_rays(rays)
+            for k in ("ent", "tri", "t", "pos", "normal"):
+                assert np.array_equal(got[k], want[k]), (shift, mode, k, int((got[k] != want[k]).sum()))
+            fo, fg = c.render(200, 120), g.render(200, 120)
+            _same(fg, fo)
+            assert fg["stats"]["cull_violations"] == 0, (shift, mode)
+            assert np.array_equal(g.cast_rays(rays[::7], 2, 0), c.cast_rays(rays[::7], 2, 0))
+
+
 def test_tile_sharding_assembles_to_full_frame(main_pair, H):
     """The N-GPU path on one GPU: each rank's compact tile buffer, concatenated
     in rank order (what the RCCL all-gather produces), de-interleaves to the
