@@ -159,20 +159,26 @@ int commit(rrt_scene* s) {
                 leaves.push_back(L);
             }
         }
-        HIP_TRY(m.d_nodes.upload(nodes.data(), nodes.size() * sizeof(rrt::DNodeI)));
         HIP_TRY(m.d_boxes.upload(boxes.data(), boxes.size() * sizeof(rrt::DBox)));
         // Leaf-ordered stream, every leaf's run aligned to kGroup entries and padded to a multiple of
         // it (pad = copy of the run's last entry, never tested: the kernels mask by the leaf's count).
         constexpr int32_t G = rrt::kGroup;
         std::vector<int32_t> refs;
         refs.reserve(T.leaf_refs.size() + (size_t)G * leaves.size());
-        for (rrt::DLeaf& L : leaves) {
+        std::vector<int32_t> leaf_node(leaves.size());
+        for (size_t k = 0; k < nn; ++k)
+            if (nodes[k].axis < 0) leaf_node[(size_t)nodes[k].right] = (int32_t)k;
+        for (size_t li = 0; li < leaves.size(); ++li) {
+            rrt::DLeaf& L = leaves[li];
             const int32_t src = L.first;
             L.first = (int32_t)refs.size();
+            nodes[(size_t)leaf_node[li]].run[0] = L.first;
+            nodes[(size_t)leaf_node[li]].run[1] = L.count;
             for (int32_t k = 0; k < L.count; ++k) refs.push_back(T.leaf_refs[(size_t)src + k]);
             while (refs.size() % G) refs.push_back(refs.back());
         }
         if (refs.size() > 0x7fffffffull - 64) return fail(RRT_E_INVALID, "mesh too large (triangle stream index exceeds 31 bits)");
+        HIP_TRY(m.d_nodes.upload(nodes.data(), nodes.size() * sizeof(rrt::DNodeI)));   // after the runs are final
         HIP_TRY(m.d_leaves.upload(leaves.data(), leaves.size() * sizeof(rrt::DLeaf)));
         HIP_TRY(m.d_refs.upload(refs.data(), refs.size() * sizeof(int32_t)));
         std::vector<rrt::DTri> stream(refs.size());

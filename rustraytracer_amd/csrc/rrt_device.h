@@ -21,7 +21,10 @@ constexpr int kMaxLevels = 18;  // max_bounce + 2 casts per path, max_bounce <= 
 //                       and rope targets may be interior nodes (kdtree.rs:23-24, 139-161).
 //   DLeaf[leaf]   80 B  box again (exit test + get_plane), ropes, range in the triangle stream.
 struct DNodeI {
-    double split;
+    union {
+        double split;    // interior node
+        int32_t run[2];  // leaf: first entry in the triangle stream, entry count (= DLeaf::first/count)
+    };
     int32_t axis;    // 0..2, or -1 for a leaf
     int32_t right;   // interior: right child node; leaf: index into DLeaf[]
 };

@@ -220,29 +220,38 @@ struct Hit {
     V3 normal;
 };
 
-// KDTree::find_point (kdtree.rs:23-33) starting at node `at`.  Returns the leaf number or -1.
+// What a descent ends on: the leaf number and its run in the triangle stream (DNodeI of a leaf
+// carries first/count in the bytes an interior node uses for its split).
+struct LeafRef {
+    int32_t leaf;    // -1 = the point is outside the box find_point started from
+    int32_t first, count;
+};
+
+// KDTree::find_point (kdtree.rs:23-33) starting at node `at`.
 // `lnodes` != nullptr: this mesh's descent array is staged in LDS (wave-uniform choice).
-RRT_DEV int32_t find_point(const DMesh& M, const DNodeI* lnodes, int32_t at, V3 p) {
+RRT_DEV LeafRef find_point(const DMesh& M, const DNodeI* lnodes, int32_t at, V3 p) {
     const RRT_GLOBAL DBox* bx = as_global(M.boxes) + at;
-    if (!box_contains(ld3g(bx->mn), ld3g(bx->mx), p)) return -1;
     if (lnodes) {
+        if (!box_contains(ld3g(bx->mn), ld3g(bx->mx), p)) return LeafRef{-1, 0, 0};
         DNodeI n = lnodes[at];
         while (n.axis >= 0) {
             CNT(3);
             at = (comp(p, n.axis) >= n.split) ? n.right : at + 1;   // pre-order: left child = at + 1
             n = lnodes[at];
         }
-        return n.right;
+        return LeafRef{n.right, n.run[0], n.run[1]};
     }
+    // global-memory descent: the first node is requested together with the box, not after its test
     const RRT_GLOBAL DNodeI* gn = as_global(M.nodes);
     double split = gn[at].split;
     int32_t axis = gn[at].axis, right = gn[at].right;
+    if (!box_contains(ld3g(bx->mn), ld3g(bx->mx), p)) return LeafRef{-1, 0, 0};
     while (axis >= 0) {
         CNT(3);
         at = (comp(p, axis) >= split) ? right : at + 1;
         split = gn[at].split; axis = gn[at].axis; right = gn[at].right;
     }
-    return right;
+    return LeafRef{right, __double2loint(split), __double2hiint(split)};
 }
 
 // get_plane (kdtree.rs:237-244)
@@ -356,20 +365,20 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, Leaf
     }
     CNT(2);
     point = point + d * 0.01;
-    int32_t leaf = find_point(M, lnodes, 0, point);
+    LeafRef lr = find_point(M, lnodes, 0, point);
     CullRay cr;
     if (CULL != 0) cr = make_cull_ray(M, o, d, inv);
     const RRT_GLOBAL DLeaf* leaves = as_global(M.leaves);
     const RRT_GLOBAL DTri* stream = as_global(M.tris);
     uint32_t visits = 0;
-    while (leaf >= 0) {
+    while (lr.leaf >= 0) {
         if (++visits > kMaxLeafVisits) {
             atomicAdd(&stats[1], 1ull);
             return;
         }
-        const RRT_GLOBAL DLeaf* L = leaves + leaf;
+        const RRT_GLOBAL DLeaf* L = leaves + lr.leaf;
         CNT(4);
-        const int32_t first = L->first, count = L->count;
+        const int32_t first = lr.first, count = lr.count;
         LeafBest best;
         best.dist = kF64Max; best.t = 0.0; best.entry = -1;
         const RRT_GLOBAL DTri* tp = stream + first;
@@ -448,7 +457,7 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, Leaf
         point = box_exit(mn, mx, point, d, inv) + d * 0.001;
         const int32_t nb = L->rope[get_plane(point, mn, mx)];
         if (nb < 0) return;
-        leaf = find_point(M, lnodes, nb, point);
+        lr = find_point(M, lnodes, nb, point);
     }
 }
 
