@@ -146,6 +146,19 @@ int rrt_add_sphere(rrt_scene* s, const double center[3], double radius, int mate
  * the tie order of its sort_unstable_by.  Returns the entity id. */
 int rrt_add_mesh(rrt_scene* s, const double* verts, const double* normals, int64_t n_triangles, int material);
 
+/* Scene::new(models, position) + world.entities.push(scene) (src/geometry/scene.rs:39-47; the
+ * scene!/entity_enum! macros scene.rs:12-29 and #[derive(Entity)] derive_entity/src/lib.rs:7-51 are
+ * the enum plumbing around it; usage commented out at src/main.rs:57-59).  `members` are ids of
+ * spheres/meshes already added: they leave the world's entity list and are reached only through
+ * the group's kd-tree over their bounding boxes (KDTree<T>::new over entities, kdtree.rs:46-51),
+ * whose collide (kdtree.rs:192-235) answers with the closest member of the first leaf in which
+ * any member is hit -- after the tree's root box passed aabb.rs:50-100, so results can differ from
+ * the flat entity loop exactly as they do in the reference.  Groups do not nest.  Entity ids
+ * reported in the id AOV remain those of the members.  The group's `position` argument is stored
+ * by the reference but never read by render; it is not part of this call.
+ * Returns the group's entity id. */
+int rrt_add_group(rrt_scene* s, const int32_t* members, int32_t n_members);
+
 /* Material::new_sky_material / CubemapBehavior::new (src/material.rs:35-42,
  * src/behavior/cubemap.rs:16-52) after the PNGs are decoded to RGB8 by the
  * host.  face index = position in the reference's maps[] array

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <variant>
 #include <vector>
 
 #include "rrt_host.h"
@@ -52,6 +53,17 @@ struct Model {                                   // model.rs:24-56
     }
 };
 
+// scene.rs:31-47 with the scene!/entity_enum! macros (scene.rs:12-29) and #[derive(Entity)]
+// (derive_entity/src/lib.rs) folded into one closed sum type: the enum those macros generate for
+// `entity_enum!(SceneType, Sphere, Model)` is exactly std::variant<Sphere, Model>, and the derived
+// `match self { V(a) => a.collide(ray) }` forwarding is what the kernels do on the entity kind.
+//     Scene::new_(Point3{0,0,0}, {Model(burger), Sphere(sphere), Sphere(sphere2)})   main.rs:57-58
+struct Scene {
+    using Member = std::variant<Sphere, Model>;
+    std::vector<Member> models; Point3 position;
+    static Scene new_(Point3 position, std::vector<Member> models) { return Scene{std::move(models), position}; }
+};
+
 // common.rs:10-15 + RayTracer::new_empty_world (tracer.rs:53-75)
 class World {
   public:
@@ -72,6 +84,16 @@ class World {
     int push(const Model& m) {
         const double p[3] = {m.position.x, m.position.y, m.position.z}, sc[3] = {m.scale.x, m.scale.y, m.scale.z};
         const int id = rrt_host_add_model(h_, m.path.c_str(), material_id(m.material), p, sc);
+        check(id);
+        return id;
+    }
+    // world.entities.push(scene)                main.rs:59: the members are reachable through the
+    // scene's kd-tree only (rrt_add_group); returns the scene's entity id
+    int push(const Scene& sc) {
+        std::vector<int32_t> ids;
+        for (const Scene::Member& m : sc.models)
+            ids.push_back(std::visit([this](const auto& e) { return this->push(e); }, m));
+        const int id = rrt_add_group(h_, ids.data(), (int32_t)ids.size());
         check(id);
         return id;
     }

@@ -59,6 +59,8 @@ def lib():
         L.orc_add_material_ext.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double]
         L.orc_add_sphere.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_double, C.c_int]
         L.orc_add_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_add_group.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_add_group.restype = C.c_int
         L.orc_set_sky_face.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]
         L.orc_set_directional_light.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]
         L.orc_set_ambient.argtypes = [C.c_void_p, C.c_double]
@@ -198,6 +200,14 @@ class OracleScene:
         n = np.ascontiguousarray(normals, dtype=np.float64).reshape(-1, 3)
         assert v.shape[0] == n.shape[0]
         return self.L.orc_add_mesh(self.h, _ptr(v), _ptr(n), v.shape[0], mat)
+
+    def add_group(self, members):
+        """Scene::new (scene.rs:39-47) over entities already added; returns the group's entity id."""
+        m = np.ascontiguousarray(members, dtype=np.int32)
+        e = self.L.orc_add_group(self.h, _ptr(m), m.size)
+        if e < 0:
+            raise ValueError("bad member list")
+        return e
 
     def set_sky(self, faces):
         for i, f in enumerate(faces):

@@ -251,7 +251,8 @@ struct Mesh {
 };
 
 // kdtree.rs:53-137
-std::unique_ptr<KdNode> build_tree(const Mesh& m, std::vector<int> ents, size_t depth, AABB box) {
+// Generic over what the items are (KDTree<T: Entity>): only their bounding boxes are consulted.
+std::unique_ptr<KdNode> build_tree(const std::vector<AABB>& item_box, std::vector<int> ents, size_t depth, AABB box) {
     const int axis = (int)(depth % 3);
     auto node = std::make_unique<KdNode>();
     node->box = box;
@@ -259,8 +260,8 @@ std::unique_ptr<KdNode> build_tree(const Mesh& m, std::vector<int> ents, size_t 
         node->leaf = std::move(ents);
         return node;
     }
-    auto mn = [&](int id) { return m.tri_box[id].mn[axis]; };
-    auto mx = [&](int id) { return m.tri_box[id].mx[axis]; };
+    auto mn = [&](int id) { return item_box[id].mn[axis]; };
+    auto mx = [&](int id) { return item_box[id].mx[axis]; };
     const size_t median = ents.size() / 2;
     // kdtree.rs:70 sort_unstable_by(|a,b| min[axis](a).partial_cmp(min[axis](b)))
     if (g_sort_mode == 0) {
@@ -291,8 +292,8 @@ std::unique_ptr<KdNode> build_tree(const Mesh& m, std::vector<int> ents, size_t 
     rb.mn.at(axis) = partition;
     node->axis = axis;
     node->partition = partition;
-    node->left = build_tree(m, std::move(ents), depth + 1, lb);
-    node->right = build_tree(m, std::move(right), depth + 1, rb);
+    node->left = build_tree(item_box, std::move(ents), depth + 1, lb);
+    node->right = build_tree(item_box, std::move(right), depth + 1, rb);
     return node;
 }
 
@@ -327,10 +328,26 @@ void make_ropes(KdNode* self, const KdNode* const in_ropes[6]) {
     }
 }
 
-void flatten(Mesh& m, KdNode* n) {
+template <class Holder>
+void flatten(Holder& m, KdNode* n) {
     n->flat_index = (int)m.flat.size();
     m.flat.push_back(n);
     if (n->axis >= 0) { flatten(m, n->left.get()); flatten(m, n->right.get()); }
+}
+
+// aabb.rs:25-39 from_entities
+inline AABB union_of(const std::vector<AABB>& boxes) {
+    AABB bb{{std::numeric_limits<double>::max(), std::numeric_limits<double>::max(), std::numeric_limits<double>::max()},
+            {std::numeric_limits<double>::lowest(), std::numeric_limits<double>::lowest(), std::numeric_limits<double>::lowest()}};
+    for (const AABB& b : boxes) {
+        if (b.mn.x < bb.mn.x) bb.mn.x = b.mn.x;
+        if (b.mn.y < bb.mn.y) bb.mn.y = b.mn.y;
+        if (b.mn.z < bb.mn.z) bb.mn.z = b.mn.z;
+        if (b.mx.x > bb.mx.x) bb.mx.x = b.mx.x;
+        if (b.mx.y > bb.mx.y) bb.mx.y = b.mx.y;
+        if (b.mx.z > bb.mx.z) bb.mx.z = b.mx.z;
+    }
+    return bb;
 }
 
 // kdtree.rs:23-33
@@ -436,13 +453,25 @@ inline Collide sphere_collide_inside(const Sphere& s, const Ray& ray) {
     return r;
 }
 
-struct Entity { int kind; int index; };  // kind 0 = sphere, 1 = mesh
+// kind 0 = sphere, 1 = mesh, 2 = group (Scene<T>, scene.rs:31-47); parent = the group an entity was
+// moved into (then world.entities no longer lists it, main.rs:57-59), -1 = top level
+struct Entity { int kind; int index; int parent = -1; };
+
+// Scene<T> (scene.rs:31-47): a KDTree over whole entities.  `members` are entity ids; the tree's
+// leaves hold positions in `members`.
+struct Group {
+    std::vector<int> members;
+    std::vector<AABB> member_box;
+    std::unique_ptr<KdNode> root;
+    std::vector<const KdNode*> flat;
+};
 struct Face { std::vector<uint8_t> rgb; uint32_t w = 0, h = 0; };
 
 struct Scene {
     std::vector<Material> mats;
     std::vector<Sphere> spheres;
     std::vector<std::unique_ptr<Mesh>> meshes;
+    std::vector<std::unique_ptr<Group>> groups;
     std::vector<Entity> ents;
     Face sky[6];
     // lighting.rs:25-32 (one DirectionalLight) ; tracer.rs:55-73
@@ -488,21 +517,64 @@ inline V3 sky_color(const Scene& sc, V3 d) {
 
 struct Primary { int ent = -1; int tri = -1; double t = 0.0; };
 
-// tracer.rs:177-190 : world-level closest hit.
+// Entity::collide of entity e (a sphere or a mesh).
+inline Collide entity_collide(const Scene& sc, int e, const Ray& ray, Counters& c) {
+    if (sc.ents[e].kind == 0) {
+        ++c.sphere_tests;
+        return (e == ray.medium) ? sphere_collide_inside(sc.spheres[sc.ents[e].index], ray)
+                                 : sphere_collide(sc.spheres[sc.ents[e].index], ray);
+    }
+    return kd_collide(*sc.meshes[sc.ents[e].index], ray, c);
+}
+
+// Scene<T>::collide = KDTree<T>::collide over entities (scene.rs:50-52, kdtree.rs:192-235).
+// *member_out = entity id of the member that answered.
+inline Collide group_collide(const Scene& sc, const Group& g, const Ray& ray, int* member_out, Counters& c) {
+    Collide none;
+    V3 entry;
+    ++c.box_tests;
+    if (!aabb_collide(g.root->box, ray.o, ray.d, &entry)) return none;
+    V3 point = add(entry, mul(ray.d, 0.01));
+    const KdNode* leaf = find_point(g.root.get(), point, c);
+    uint32_t visits = 0;
+    while (true) {
+        if (!leaf) return none;
+        if (++visits > MAX_LEAF_VISITS) { ++c.overflow; return none; }
+        double min_d = std::numeric_limits<double>::max();
+        Collide best; int best_ent = -1;
+        for (int k : leaf->leaf) {
+            const int e = g.members[(size_t)k];
+            const Collide r = entity_collide(sc, e, ray, c);
+            if (r.hit) {
+                const double dist = mag2(sub(r.pos, ray.o));
+                if (dist < min_d) { min_d = dist; best = r; best_ent = e; }
+            }
+        }
+        if (best.hit) { *member_out = best_ent; return best; }
+        V3 exitp;
+        ++c.box_tests;
+        aabb_collide(leaf->box, point, ray.d, &exitp);
+        point = add(exitp, mul(ray.d, 0.001));
+        const KdNode* nb = leaf->ropes[get_plane(point, leaf->box)];
+        if (!nb) return none;
+        leaf = find_point(nb, point, c);
+    }
+}
+
+// tracer.rs:177-190 : world-level closest hit.  *ent_out is the sphere or mesh that was hit (for a
+// group: its answering member).
 inline Collide closest_hit(const Scene& sc, const Ray& ray, int* ent_out, Counters& c) {
     double min_d = std::numeric_limits<double>::max();
     Collide best; int best_ent = -1;
     for (size_t e = 0; e < sc.ents.size(); ++e) {
+        if (sc.ents[e].parent >= 0) continue;        // lives inside a group, not in world.entities
         Collide r;
-        if (sc.ents[e].kind == 0) {
-            ++c.sphere_tests;
-            r = ((int)e == ray.medium) ? sphere_collide_inside(sc.spheres[sc.ents[e].index], ray)
-                                       : sphere_collide(sc.spheres[sc.ents[e].index], ray);
-        }
-        else r = kd_collide(*sc.meshes[sc.ents[e].index], ray, c);
+        int who = (int)e;
+        if (sc.ents[e].kind == 2) r = group_collide(sc, *sc.groups[sc.ents[e].index], ray, &who, c);
+        else r = entity_collide(sc, (int)e, ray, c);
         if (r.hit) {
             const double dist = mag2(sub(r.pos, ray.o));
-            if (dist < min_d) { min_d = dist; best = r; best_ent = (int)e; }
+            if (dist < min_d) { min_d = dist; best = r; best_ent = who; }
         }
     }
     *ent_out = best_ent;
@@ -677,21 +749,10 @@ int orc_add_mesh(void* h, const double* verts, const double* normals, int n, int
         t.normal = V3{normals[3 * i + 0], normals[3 * i + 1], normals[3 * i + 2]};
         m->tri_box[i] = t.bbox();
     }
-    // aabb.rs:25-39 from_entities
-    AABB bb{{std::numeric_limits<double>::max(), std::numeric_limits<double>::max(), std::numeric_limits<double>::max()},
-            {std::numeric_limits<double>::lowest(), std::numeric_limits<double>::lowest(), std::numeric_limits<double>::lowest()}};
-    for (int i = 0; i < n; ++i) {
-        const AABB& b = m->tri_box[i];
-        if (b.mn.x < bb.mn.x) bb.mn.x = b.mn.x;
-        if (b.mn.y < bb.mn.y) bb.mn.y = b.mn.y;
-        if (b.mn.z < bb.mn.z) bb.mn.z = b.mn.z;
-        if (b.mx.x > bb.mx.x) bb.mx.x = b.mx.x;
-        if (b.mx.y > bb.mx.y) bb.mx.y = b.mx.y;
-        if (b.mx.z > bb.mx.z) bb.mx.z = b.mx.z;
-    }
+    const AABB bb = union_of(m->tri_box);
     std::vector<int> ids(n);
     for (int i = 0; i < n; ++i) ids[i] = i;
-    m->root = build_tree(*m, std::move(ids), 0, bb);   // kdtree.rs:46-51
+    m->root = build_tree(m->tri_box, std::move(ids), 0, bb);   // kdtree.rs:46-51
     const KdNode* none[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     make_ropes(m->root.get(), none);
     flatten(*m, m->root.get());
@@ -699,6 +760,39 @@ int orc_add_mesh(void* h, const double* verts, const double* normals, int n, int
     s->meshes.push_back(std::move(m));
     s->ents.push_back(Entity{1, (int)s->meshes.size() - 1});
     return (int)s->ents.size() - 1;
+}
+
+// Scene::new (scene.rs:39-47) over entities already added; they leave the top-level list and the
+// group takes the next entity id.  Returns that id, or -1 for a bad member list.
+int orc_add_group(void* h, const int32_t* members, int n) {
+    Scene* s = (Scene*)h;
+    auto g = std::make_unique<Group>();
+    for (int i = 0; i < n; ++i) {
+        const int e = members[i];
+        if (e < 0 || e >= (int)s->ents.size() || s->ents[e].kind == 2 || s->ents[e].parent >= 0) return -1;
+        for (int j = 0; j < i; ++j) if (members[j] == e) return -1;
+        AABB b;
+        if (s->ents[e].kind == 0) {                       // sphere.rs:49-54
+            const Sphere& sp = s->spheres[s->ents[e].index];
+            b = AABB{{sp.c.x - sp.r, sp.c.y - sp.r, sp.c.z - sp.r}, {sp.c.x + sp.r, sp.c.y + sp.r, sp.c.z + sp.r}};
+        } else {                                          // model.rs:68-70: the tree's root box
+            b = s->meshes[s->ents[e].index]->root->box;
+        }
+        g->members.push_back(e);
+        g->member_box.push_back(b);
+    }
+    if (n <= 0) return -1;
+    std::vector<int> ids(n);
+    for (int i = 0; i < n; ++i) ids[i] = i;
+    g->root = build_tree(g->member_box, std::move(ids), 0, union_of(g->member_box));
+    const KdNode* none[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    make_ropes(g->root.get(), none);
+    flatten(*g, g->root.get());
+    const int id = (int)s->ents.size();
+    for (int e : g->members) s->ents[e].parent = id;
+    s->groups.push_back(std::move(g));
+    s->ents.push_back(Entity{2, (int)s->groups.size() - 1, -1});
+    return id;
 }
 
 void orc_set_sky_face(void* h, int face, const uint8_t* rgb, uint32_t w, uint32_t hgt) {
@@ -717,21 +811,25 @@ void orc_set_directional_light(void* h, const double dir[3], const double color[
 void orc_set_ambient(void* h, double a) { ((Scene*)h)->ambient = a; }
 
 // ---- flattened-tree export (pre-order), for comparison with the product's builder
+// (a mesh's tree over its triangles, or a group's tree over its members)
+static const std::vector<const KdNode*>& flat_of(Scene* s, int ent) {
+    return s->ents[ent].kind == 2 ? s->groups[s->ents[ent].index]->flat : s->meshes[s->ents[ent].index]->flat;
+}
 void orc_mesh_tree_sizes(void* h, int ent, int* n_nodes, int* n_leaf_refs) {
     Scene* s = (Scene*)h;
-    const Mesh& m = *s->meshes[s->ents[ent].index];
+    const std::vector<const KdNode*>& flat = flat_of(s, ent);
     int refs = 0;
-    for (const KdNode* n : m.flat) if (n->axis < 0) refs += (int)n->leaf.size();
-    *n_nodes = m.n_nodes; *n_leaf_refs = refs;
+    for (const KdNode* n : flat) if (n->axis < 0) refs += (int)n->leaf.size();
+    *n_nodes = (int)flat.size(); *n_leaf_refs = refs;
 }
 // boxes: 6 doubles/node; split: 1/node; axis: 1/node (-1 leaf); child: 2/node
 // (interior: left,right; leaf: first,count into leaf_refs); ropes: 6/node (-1 none).
 void orc_mesh_tree_export(void* h, int ent, double* boxes, double* split, int* axis, int* child, int* ropes, int* leaf_refs) {
     Scene* s = (Scene*)h;
-    const Mesh& m = *s->meshes[s->ents[ent].index];
+    const std::vector<const KdNode*>& flat = flat_of(s, ent);
     int cursor = 0;
-    for (size_t i = 0; i < m.flat.size(); ++i) {
-        const KdNode* n = m.flat[i];
+    for (size_t i = 0; i < flat.size(); ++i) {
+        const KdNode* n = flat[i];
         boxes[6 * i + 0] = n->box.mn.x; boxes[6 * i + 1] = n->box.mn.y; boxes[6 * i + 2] = n->box.mn.z;
         boxes[6 * i + 3] = n->box.mx.x; boxes[6 * i + 4] = n->box.mx.y; boxes[6 * i + 5] = n->box.mx.z;
         split[i] = n->partition; axis[i] = n->axis;

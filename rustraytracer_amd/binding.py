@@ -39,7 +39,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "rrt_last_error", "rrt_version", "rrt_set_device", "rrt_device_image_support",
     "rrt_default_camera", "rrt_default_settings", "rrt_scene_create", "rrt_scene_destroy",
-    "rrt_add_material", "rrt_add_material_ext", "rrt_add_sphere", "rrt_add_mesh", "rrt_set_sky_face",
+    "rrt_add_material", "rrt_add_material_ext", "rrt_add_sphere", "rrt_add_mesh", "rrt_add_group", "rrt_set_sky_face",
     "rrt_set_directional_light", "rrt_set_ambient", "rrt_set_work_budget", "rrt_set_cull_mode",
     "rrt_scene_commit",
     "rrt_render", "rrt_render_device", "rrt_tile_slots", "rrt_assemble_tiles",
@@ -81,6 +81,7 @@ def _load():
     L.rrt_add_material_ext.argtypes = [vp, dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double]
     L.rrt_add_sphere.argtypes = [vp, dp, C.c_double, i32]
     L.rrt_add_mesh.argtypes = [vp, vp, vp, i64, i32]
+    L.rrt_add_group.argtypes = [vp, vp, i32]
     L.rrt_set_sky_face.argtypes = [vp, i32, vp, u32, u32]
     L.rrt_set_directional_light.argtypes = [vp, dp, dp, C.c_double]
     L.rrt_set_ambient.argtypes = [vp, C.c_double]

@@ -27,7 +27,6 @@ inline double max3(double a, double b, double c) { return std::fmax(a, std::fmax
 }  // namespace
 
 KdTreeFlat build_kd_tree(const double* verts, int64_t n_tris) {
-    KdTreeFlat T;
     // Triangle::bounding_box (src/geometry/triangle.rs:60-65)
     std::vector<double> tmin((size_t)n_tris * 3), tmax((size_t)n_tris * 3);
     for (int64_t i = 0; i < n_tris; ++i) {
@@ -37,6 +36,11 @@ KdTreeFlat build_kd_tree(const double* verts, int64_t n_tris) {
             tmax[3 * i + a] = max3(v[a], v[3 + a], v[6 + a]);
         }
     }
+    return build_kd_tree_boxes(tmin, tmax, n_tris);
+}
+
+KdTreeFlat build_kd_tree_boxes(const std::vector<double>& tmin, const std::vector<double>& tmax, int64_t n_tris) {
+    KdTreeFlat T;
     // AABB::from_entities (src/geometry/aabb.rs:25-39)
     Box root;
     for (int a = 0; a < 3; ++a) {

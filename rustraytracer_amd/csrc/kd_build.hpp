@@ -32,4 +32,9 @@ struct KdTreeFlat {
 // verts: 9 doubles per triangle.  Returns the flat tree.
 KdTreeFlat build_kd_tree(const double* verts, int64_t n_tris);
 
+// KDTree<T: Entity> is generic (kdtree.rs:45): the build consults nothing but each item's
+// bounding_box().  item_min / item_max: 3 doubles per item; leaf_refs then holds item numbers.
+// Used for triangles (above) and for Scene<T>'s tree over whole entities (scene.rs:39-47).
+KdTreeFlat build_kd_tree_boxes(const std::vector<double>& item_min, const std::vector<double>& item_max, int64_t n_items);
+
 }  // namespace rrt

@@ -65,6 +65,13 @@ struct HostMesh {
     DevBuf d_nodes, d_boxes, d_leaves, d_refs, d_tris, d_normals, d_cull, d_grp;
 };
 
+// Scene<T> (scene.rs:31-47): kd-tree over member entities
+struct HostGroup {
+    std::vector<int32_t> members;   // entity ids, in the order given (= item numbers of the tree)
+    rrt::KdTreeFlat tree;
+    DevBuf d_nodes, d_boxes, d_leaves, d_members;
+};
+
 struct SkyFace {
     std::vector<uint8_t> rgb;
     uint32_t w = 0, h = 0;
@@ -87,6 +94,8 @@ struct rrt_scene {
     std::vector<rrt::DMaterial> mats;
     std::vector<rrt::DSphere> spheres;
     std::vector<std::unique_ptr<HostMesh>> meshes;
+    std::vector<std::unique_ptr<HostGroup>> groups;
+    std::vector<double> sphere_radius;   // Sphere::bounding_box needs r, the kernels only r^2
     std::vector<rrt::DEntity> ents;
     SkyFace sky[6];
     bool has_light = false;
@@ -96,7 +105,7 @@ struct rrt_scene {
     int cull_mode = 1;
 
     bool dirty = true;
-    DevBuf d_ents, d_spheres, d_meshes, d_mats;
+    DevBuf d_ents, d_spheres, d_meshes, d_mats, d_groups;
     rrt::DScene dscene{};
 
     // work buffers
@@ -247,6 +256,51 @@ int commit(rrt_scene* s) {
         dm[i].n_nodes = T.n_nodes();
     }
     HIP_TRY(s->d_meshes.upload(dm.data(), dm.size() * sizeof(rrt::DMesh)));
+    std::vector<rrt::DGroup> dg(s->groups.size());
+    for (size_t i = 0; i < s->groups.size(); ++i) {
+        HostGroup& g = *s->groups[i];
+        const rrt::KdTreeFlat& T = g.tree;
+        const size_t nn = (size_t)T.n_nodes();
+        std::vector<rrt::DNodeI> nodes(nn);
+        std::vector<rrt::DBox> boxes(nn);
+        std::vector<rrt::DLeaf> leaves;
+        for (size_t k = 0; k < nn; ++k) {
+            for (int a = 0; a < 3; ++a) {
+                boxes[k].mn[a] = T.boxes[6 * k + a];
+                boxes[k].mx[a] = T.boxes[6 * k + 3 + a];
+            }
+            nodes[k].split = T.split[k];
+            nodes[k].axis = T.axis[k];
+            if (T.axis[k] >= 0) {
+                if (T.child[2 * k] != (int32_t)k + 1) return fail(RRT_E_STATE, "kd-tree is not in pre-order");
+                nodes[k].right = T.child[2 * k + 1];
+            } else {
+                rrt::DLeaf L{};
+                for (int a = 0; a < 3; ++a) {
+                    L.mn[a] = boxes[k].mn[a];
+                    L.mx[a] = boxes[k].mx[a];
+                }
+                for (int r = 0; r < 6; ++r) L.rope[r] = T.ropes[6 * k + r];
+                L.first = T.child[2 * k];
+                L.count = T.child[2 * k + 1];
+                nodes[k].run[0] = L.first;
+                nodes[k].run[1] = L.count;
+                nodes[k].right = (int32_t)leaves.size();
+                leaves.push_back(L);
+            }
+        }
+        std::vector<int32_t> member_ids(T.leaf_refs.size());
+        for (size_t j = 0; j < member_ids.size(); ++j) member_ids[j] = g.members[(size_t)T.leaf_refs[j]];
+        HIP_TRY(g.d_nodes.upload(nodes.data(), nodes.size() * sizeof(rrt::DNodeI)));
+        HIP_TRY(g.d_boxes.upload(boxes.data(), boxes.size() * sizeof(rrt::DBox)));
+        HIP_TRY(g.d_leaves.upload(leaves.data(), leaves.size() * sizeof(rrt::DLeaf)));
+        HIP_TRY(g.d_members.upload(member_ids.data(), member_ids.size() * sizeof(int32_t)));
+        dg[i].nodes = g.d_nodes.as<rrt::DNodeI>();
+        dg[i].boxes = g.d_boxes.as<rrt::DBox>();
+        dg[i].leaves = g.d_leaves.as<rrt::DLeaf>();
+        dg[i].members = g.d_members.as<int32_t>();
+    }
+    HIP_TRY(s->d_groups.upload(dg.data(), dg.size() * sizeof(rrt::DGroup)));
     HIP_TRY(s->d_spheres.upload(s->spheres.data(), s->spheres.size() * sizeof(rrt::DSphere)));
     HIP_TRY(s->d_mats.upload(s->mats.data(), s->mats.size() * sizeof(rrt::DMaterial)));
     HIP_TRY(s->d_ents.upload(s->ents.data(), s->ents.size() * sizeof(rrt::DEntity)));
@@ -255,6 +309,8 @@ int commit(rrt_scene* s) {
     d.spheres = s->d_spheres.as<rrt::DSphere>();
     d.meshes = s->d_meshes.as<rrt::DMesh>();
     d.mats = s->d_mats.as<rrt::DMaterial>();
+    d.groups = s->d_groups.as<rrt::DGroup>();
+    d.n_groups = (int32_t)s->groups.size();
     d.n_ents = (int32_t)s->ents.size();
     d.has_light = s->has_light ? 1 : 0;
     for (int a = 0; a < 3; ++a) {
@@ -523,6 +579,7 @@ int rrt_add_sphere(rrt_scene* s, const double center[3], double radius, int mate
     sp.r2 = radius * radius;  // radius.powi(2), sphere.rs:21
     sp.material = material;
     s->spheres.push_back(sp);
+    s->sphere_radius.push_back(radius);
     s->ents.push_back(rrt::DEntity{0, (int32_t)s->spheres.size() - 1});
     s->dirty = true;
     return (int)s->ents.size() - 1;
@@ -548,6 +605,42 @@ int rrt_add_mesh(rrt_scene* s, const double* verts, const double* normals, int64
     m->tree = rrt::build_kd_tree(verts, n);
     s->meshes.push_back(std::move(m));
     s->ents.push_back(rrt::DEntity{1, (int32_t)s->meshes.size() - 1});
+    s->dirty = true;
+    return (int)s->ents.size() - 1;
+}
+
+int rrt_add_group(rrt_scene* s, const int32_t* members, int32_t n) {
+    if (!s || !members) return fail(RRT_E_INVALID, "null argument");
+    if (n <= 0) return fail(RRT_E_INVALID, "a group needs at least one member");
+    auto g = std::make_unique<HostGroup>();
+    std::vector<double> mn((size_t)n * 3), mx((size_t)n * 3);
+    for (int32_t i = 0; i < n; ++i) {
+        const int32_t e = members[i];
+        if (e < 0 || e >= (int32_t)s->ents.size()) return fail(RRT_E_INVALID, "unknown entity id in group");
+        const rrt::DEntity ent = s->ents[(size_t)e];
+        if (ent.kind != 0 && ent.kind != 1) return fail(RRT_E_INVALID, "group members must be top-level spheres or meshes");
+        for (int32_t j = 0; j < i; ++j)
+            if (members[j] == e) return fail(RRT_E_INVALID, "entity listed twice in group");
+        if (ent.kind == 0) {   // Sphere::bounding_box, sphere.rs:49-54
+            const rrt::DSphere& sp = s->spheres[(size_t)ent.index];
+            const double r = s->sphere_radius[(size_t)ent.index];
+            for (int a = 0; a < 3; ++a) {
+                mn[3 * (size_t)i + a] = sp.c[a] - r;
+                mx[3 * (size_t)i + a] = sp.c[a] + r;
+            }
+        } else {               // Model::bounding_box = from_entities(triangles), model.rs:51,68-70
+            const rrt::KdTreeFlat& T = s->meshes[(size_t)ent.index]->tree;
+            for (int a = 0; a < 3; ++a) {
+                mn[3 * (size_t)i + a] = T.boxes[(size_t)a];
+                mx[3 * (size_t)i + a] = T.boxes[3 + (size_t)a];
+            }
+        }
+        g->members.push_back(e);
+    }
+    g->tree = rrt::build_kd_tree_boxes(mn, mx, n);     // KDTree::new(models), scene.rs:43
+    for (int32_t e : g->members) s->ents[(size_t)e].kind |= rrt::kEntityMember;
+    s->groups.push_back(std::move(g));
+    s->ents.push_back(rrt::DEntity{2, (int32_t)s->groups.size() - 1});
     s->dirty = true;
     return (int)s->ents.size() - 1;
 }
@@ -723,10 +816,18 @@ int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) {
     return RRT_OK;
 }
 
+// the tree of a mesh (over its triangles) or of a group (over its members, numbered in the order given)
+static const rrt::KdTreeFlat* tree_of(const rrt_scene* s, int entity) {
+    if (!s || entity < 0 || entity >= (int)s->ents.size()) return nullptr;
+    const rrt::DEntity ent = s->ents[(size_t)entity];
+    const int kind = ent.kind & ~rrt::kEntityMember;
+    if (kind == 1) return &s->meshes[(size_t)ent.index]->tree;
+    if (kind == 2) return &s->groups[(size_t)ent.index]->tree;
+    return nullptr;
+}
 int rrt_mesh_tree_sizes(const rrt_scene* s, int entity, int32_t* n_nodes, int32_t* n_leaf_refs) {
-    if (!s || entity < 0 || entity >= (int)s->ents.size() || s->ents[(size_t)entity].kind != 1)
-        return fail(RRT_E_INVALID, "entity is not a mesh");
-    const rrt::KdTreeFlat& T = s->meshes[(size_t)s->ents[(size_t)entity].index]->tree;
+    if (!tree_of(s, entity)) return fail(RRT_E_INVALID, "entity is not a mesh or a group");
+    const rrt::KdTreeFlat& T = *tree_of(s, entity);
     if (n_nodes) *n_nodes = T.n_nodes();
     if (n_leaf_refs) *n_leaf_refs = (int32_t)T.leaf_refs.size();
     return RRT_OK;
@@ -734,9 +835,8 @@ int rrt_mesh_tree_sizes(const rrt_scene* s, int entity, int32_t* n_nodes, int32_
 
 int rrt_mesh_tree_export(const rrt_scene* s, int entity, double* boxes, double* split, int32_t* axis, int32_t* child,
                          int32_t* ropes, int32_t* leaf_refs) {
-    if (!s || entity < 0 || entity >= (int)s->ents.size() || s->ents[(size_t)entity].kind != 1)
-        return fail(RRT_E_INVALID, "entity is not a mesh");
-    const rrt::KdTreeFlat& T = s->meshes[(size_t)s->ents[(size_t)entity].index]->tree;
+    if (!tree_of(s, entity)) return fail(RRT_E_INVALID, "entity is not a mesh or a group");
+    const rrt::KdTreeFlat& T = *tree_of(s, entity);
     if (boxes) std::memcpy(boxes, T.boxes.data(), T.boxes.size() * 8);
     if (split) std::memcpy(split, T.split.data(), T.split.size() * 8);
     if (axis) std::memcpy(axis, T.axis.data(), T.axis.size() * 4);

@@ -97,8 +97,18 @@ struct DMaterial {
 };
 
 struct DEntity {
-    int32_t kind;   // 0 sphere, 1 mesh
+    int32_t kind;   // 0 sphere, 1 mesh, 2 group (Scene<T>); | kEntityMember when it lives inside a group
     int32_t index;
+};
+constexpr int32_t kEntityMember = 0x100;
+
+// Scene<T> (src/geometry/scene.rs:31-47): a kd-tree over whole entities, same node/box/leaf arrays as
+// a mesh's tree; a leaf's run indexes `members` (entity ids).
+struct DGroup {
+    const DNodeI* nodes;
+    const DBox* boxes;
+    const DLeaf* leaves;
+    const int32_t* members;
 };
 
 struct DScene {
@@ -106,6 +116,9 @@ struct DScene {
     const DSphere* spheres;
     const DMesh* meshes;
     const DMaterial* mats;
+    const DGroup* groups;
+    int32_t n_groups;
+    int32_t pad1;
     int32_t n_ents;
     int32_t has_light;
     double light_dir[3];

@@ -229,8 +229,8 @@ struct LeafRef {
 
 // KDTree::find_point (kdtree.rs:23-33) starting at node `at`.
 // `lnodes` != nullptr: this mesh's descent array is staged in LDS (wave-uniform choice).
-RRT_DEV LeafRef find_point(const DMesh& M, const DNodeI* lnodes, int32_t at, V3 p) {
-    const RRT_GLOBAL DBox* bx = as_global(M.boxes) + at;
+RRT_DEV LeafRef find_point(const DNodeI* nodes, const DBox* boxes, const DNodeI* lnodes, int32_t at, V3 p) {
+    const RRT_GLOBAL DBox* bx = as_global(boxes) + at;
     if (lnodes) {
         if (!box_contains(ld3g(bx->mn), ld3g(bx->mx), p)) return LeafRef{-1, 0, 0};
         DNodeI n = lnodes[at];
@@ -242,7 +242,7 @@ RRT_DEV LeafRef find_point(const DMesh& M, const DNodeI* lnodes, int32_t at, V3 
         return LeafRef{n.right, n.run[0], n.run[1]};
     }
     // global-memory descent: the first node is requested together with the box, not after its test
-    const RRT_GLOBAL DNodeI* gn = as_global(M.nodes);
+    const RRT_GLOBAL DNodeI* gn = as_global(nodes);
     double split = gn[at].split;
     int32_t axis = gn[at].axis, right = gn[at].right;
     if (!box_contains(ld3g(bx->mn), ld3g(bx->mx), p)) return LeafRef{-1, 0, 0};
@@ -365,7 +365,7 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, Leaf
     }
     CNT(2);
     point = point + d * 0.01;
-    LeafRef lr = find_point(M, lnodes, 0, point);
+    LeafRef lr = find_point(M.nodes, M.boxes, lnodes, 0, point);
     CullRay cr;
     if (CULL != 0) cr = make_cull_ray(M, o, d, inv);
     const RRT_GLOBAL DLeaf* leaves = as_global(M.leaves);
@@ -457,7 +457,7 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, Leaf
         point = box_exit(mn, mx, point, d, inv) + d * 0.001;
         const int32_t nb = L->rope[get_plane(point, mn, mx)];
         if (nb < 0) return;
-        lr = find_point(M, lnodes, nb, point);
+        lr = find_point(M.nodes, M.boxes, lnodes, nb, point);
     }
 }
 
@@ -496,31 +496,94 @@ struct Closest {
     int32_t entry;   // mesh: winning stream entry
 };
 
-// The entity loop of RayTracer::cast (tracer.rs:178-190)
+// Entity::collide of a sphere or a mesh + the "closer than what we have" update that both the world
+// loop (tracer.rs:183-188) and a kd leaf over entities (kdtree.rs:204-211) apply: strict <, so the
+// first of equals stays.
 template <int CULL>
+RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, int32_t e, DEntity ent, V3 o, V3 d, int32_t medium,
+                            Closest* best, unsigned long long* stats) {
+    if (ent.kind == 0) {
+        double t;
+        const bool got = (e == medium) ? sphere_collide_inside(sc.spheres + ent.index, o, d, &t)
+                                       : sphere_collide(sc.spheres + ent.index, o, d, &t);
+        if (got) {
+            const V3 pos = o + d * t;                  // sphere.rs:39
+            const double dist = mag2(pos - o);         // tracer.rs:184
+            if (dist < best->dist) { best->dist = dist; best->t = t; best->ent = e; best->entry = -1; }
+        }
+    } else {
+        const DMesh M = sc.meshes[ent.index];
+        LeafBest h;
+        mesh_collide<CULL>(M, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, &h, stats);
+        // same |pos - origin|^2 as the leaf-level metric (kdtree.rs:206 == tracer.rs:184)
+        if (h.entry >= 0 && h.dist < best->dist) {
+            best->dist = h.dist; best->t = h.t; best->ent = e; best->entry = h.entry;
+        }
+    }
+}
+
+// Scene<T>::collide (scene.rs:50-52) = KDTree<T>::collide (kdtree.rs:192-235) with whole entities in
+// the leaves: the closest member of the first leaf in which any member answers.  `out` receives
+// that member (its entity id), or ent = -1.
+template <int CULL>
+RRT_DEV void group_collide(const DScene& sc, const DGroup& G, const DNodeI* lnodes, V3 o, V3 d, int32_t medium,
+                           Closest* out, unsigned long long* stats) {
+    out->dist = kF64Max; out->t = 0.0; out->ent = -1; out->entry = -1;
+    const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
+    V3 point;
+    {
+        const RRT_GLOBAL DBox* rb = as_global(G.boxes);
+        if (!box_collide(ld3g(rb->mn), ld3g(rb->mx), o, d, inv, &point)) return;
+    }
+    point = point + d * 0.01;
+    LeafRef lr = find_point(G.nodes, G.boxes, nullptr, 0, point);
+    const RRT_GLOBAL int32_t* members = as_global(G.members);
+    uint32_t visits = 0;
+    while (lr.leaf >= 0) {
+        if (++visits > kMaxLeafVisits) {
+            atomicAdd(&stats[1], 1ull);
+            return;
+        }
+        Closest best;
+        best.dist = kF64Max; best.t = 0.0; best.ent = -1; best.entry = -1;
+        for (int32_t k = 0; k < lr.count; ++k) {
+            const int32_t e = members[lr.first + k];
+            DEntity ent = sc.ents[e];
+            ent.kind &= ~kEntityMember;            // 0 sphere or 1 mesh (rrt_add_group admits nothing else)
+            entity_collide<CULL>(sc, lnodes, e, ent, o, d, medium, &best, stats);
+        }
+        if (best.ent >= 0) {
+            *out = best;
+            return;
+        }
+        const RRT_GLOBAL DLeaf* L = as_global(G.leaves) + lr.leaf;
+        const V3 mn = ld3g(L->mn), mx = ld3g(L->mx);
+        point = box_exit(mn, mx, point, d, inv) + d * 0.001;
+        const int32_t nb = L->rope[get_plane(point, mn, mx)];
+        if (nb < 0) return;
+        lr = find_point(G.nodes, G.boxes, nullptr, nb, point);
+    }
+}
+
+// The entity loop of RayTracer::cast (tracer.rs:178-190).  GROUPS: the scene holds Scene<T>
+// entities (kind 2); their members carry kEntityMember and are not in world.entities.
+template <int CULL, bool GROUPS>
 RRT_DEV void closest_hit(const DScene& sc, const DNodeI* lnodes, V3 o, V3 d, int32_t medium, Closest* best,
                          unsigned long long* stats) {
     best->dist = kF64Max; best->t = 0.0; best->ent = -1; best->entry = -1;
     for (int32_t e = 0; e < sc.n_ents; ++e) {
-        const DEntity ent = sc.ents[e];
-        if (ent.kind == 0) {
-            double t;
-            const bool got = (e == medium) ? sphere_collide_inside(sc.spheres + ent.index, o, d, &t)
-                                           : sphere_collide(sc.spheres + ent.index, o, d, &t);
-            if (got) {
-                const V3 pos = o + d * t;                  // sphere.rs:39
-                const double dist = mag2(pos - o);         // tracer.rs:184
-                if (dist < best->dist) { best->dist = dist; best->t = t; best->ent = e; best->entry = -1; }
-            }
-        } else {
-            const DMesh M = sc.meshes[ent.index];
-            LeafBest h;
-            mesh_collide<CULL>(M, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, &h, stats);
-            // same |pos - origin|^2 as the leaf-level metric (kdtree.rs:206 == tracer.rs:184)
-            if (h.entry >= 0 && h.dist < best->dist) {
-                best->dist = h.dist; best->t = h.t; best->ent = e; best->entry = h.entry;
+        DEntity ent = sc.ents[e];
+        if (GROUPS) {
+            if (ent.kind & kEntityMember) continue;
+            if (ent.kind == 2) {
+                const DGroup G = sc.groups[ent.index];
+                Closest h;
+                group_collide<CULL>(sc, G, lnodes, o, d, medium, &h, stats);
+                if (h.ent >= 0 && h.dist < best->dist) *best = h;
+                continue;
             }
         }
+        entity_collide<CULL>(sc, lnodes, e, ent, o, d, medium, best, stats);
     }
 }
 
@@ -531,7 +594,8 @@ RRT_DEV void finish_hit(const DScene& sc, V3 o, V3 d, const Closest& c, Hit* h) 
     h->tri = -1; h->mat = -1; h->t = 0.0;
     h->pos = mk(0., 0., 0.); h->normal = mk(0., 0., 0.);
     if (!h->hit) return;
-    const DEntity ent = sc.ents[c.ent];
+    DEntity ent = sc.ents[c.ent];
+    ent.kind &= ~kEntityMember;
     h->t = c.t;
     h->pos = o + d * c.t;
     if (ent.kind == 0) {
@@ -701,7 +765,7 @@ RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y
 }
 
 // One cast() (tracer.rs:177-211) of path `path` at depth `bounce`.
-template <bool PRIMARY, int CULL>
+template <bool PRIMARY, int CULL, bool GROUPS>
 RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk, const DFrame& fr, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
                          uint32_t pixel, uint32_t sample) {
@@ -712,7 +776,7 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
     if (active) {
         Closest c;
         CNT(0);
-        closest_hit<CULL>(sc, lnodes, o, d, medium, &c, wk.stats);
+        closest_hit<CULL, GROUPS>(sc, lnodes, o, d, medium, &c, wk.stats);
         Hit h;
         finish_hit(sc, o, d, c, &h);
         const int32_t ent = c.ent;
@@ -732,7 +796,7 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
                 wk.recA[r] = A.x; wk.recA[r + P] = A.y; wk.recA[r + 2 * P] = A.z;
                 wk.recP[r] = Pm.x; wk.recP[r + P] = Pm.y; wk.recP[r + 2 * P] = Pm.z;
                 wk.recR[(size_t)bounce * P + path] = m.mixR;
-                continuation(fr, m, h.pos, h.normal, d, sc.ents[ent].kind == 0, ent, bounce, pixel, sample, &ro, &rd,
+                continuation(fr, m, h.pos, h.normal, d, (sc.ents[ent].kind & ~kEntityMember) == 0, ent, bounce, pixel, sample, &ro, &rd,
                              &medium);
             } else {
                 col = A + Pm;   // Reflection returned None (reflection.rs:26-28) or was pruned
@@ -778,7 +842,7 @@ RRT_DEV const DNodeI* stage_nodes(const DScene& sc, unsigned char* smem) {
 
 // Persistent blocks: block b takes path tiles b, b + grid, ... (neighbouring tiles, which cost
 // about the same, go to different blocks), so the LDS staging is paid once per block.
-template <int CULL>
+template <int CULL, bool GROUPS>
 __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
     extern __shared__ __align__(16) unsigned char smem[];
     const DNodeI* lnodes = stage_nodes(sc, smem);
@@ -791,11 +855,11 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         const uint32_t sample = fr.s0 + s_local;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         if (active) primary_ray(fr, x, y, sample, &o, &d);
-        process_ray<true, CULL>(sc, lnodes, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample);
+        process_ray<true, CULL, GROUPS>(sc, lnodes, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample);
     }
 }
 
-template <int CULL>
+template <int CULL, bool GROUPS>
 __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = wk.q_count[bounce];
@@ -827,7 +891,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
             pixel = y * fr.width + x;
             sample = fr.s0 + s_local;
         }
-        process_ray<false, CULL>(sc, lnodes, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, pixel, sample);
+        process_ray<false, CULL, GROUPS>(sc, lnodes, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, pixel, sample);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&wk.stats[0], (unsigned long long)count);
@@ -884,6 +948,7 @@ __global__ __launch_bounds__(256) void k_assemble(const uint8_t* g, uint32_t w, 
     out[3 * (size_t)px] = g[src]; out[3 * (size_t)px + 1] = g[src + 1]; out[3 * (size_t)px + 2] = g[src + 2];
 }
 
+template <bool GROUPS>
 __global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* rays, int64_t n, int32_t* ent,
                                                     int32_t* tri, double* t, double* pos, double* nrm,
                                                     unsigned long long* stats) {
@@ -891,9 +956,9 @@ __global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* ray
     if (i >= n) return;
     const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
     Closest c;
-    if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, -1, &c, stats);
-    else if (sc.cull_mode == 1) closest_hit<1>(sc, nullptr, o, d, -1, &c, stats);
-    else closest_hit<2>(sc, nullptr, o, d, -1, &c, stats);
+    if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, nullptr, o, d, -1, &c, stats);
+    else if (sc.cull_mode == 1) closest_hit<1, GROUPS>(sc, nullptr, o, d, -1, &c, stats);
+    else closest_hit<2, GROUPS>(sc, nullptr, o, d, -1, &c, stats);
     Hit h;
     finish_hit(sc, o, d, c, &h);
     const int32_t e = c.ent;
@@ -905,6 +970,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* ray
 }
 
 // cast() as one thread per ray with a private record stack (test / probe API).
+template <bool GROUPS>
 __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays, int64_t n, uint32_t max_bounce,
                                                    uint32_t prune, double* color, unsigned long long* stats) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -918,8 +984,8 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
     V3 col;
     for (;;) {
         Closest c;
-        if (sc.cull_mode == 0) closest_hit<0>(sc, nullptr, o, d, medium, &c, stats);
-        else closest_hit<2>(sc, nullptr, o, d, medium, &c, stats);
+        if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, nullptr, o, d, medium, &c, stats);
+        else closest_hit<2, GROUPS>(sc, nullptr, o, d, medium, &c, stats);
         Hit h;
         finish_hit(sc, o, d, c, &h);
         if (!h.hit) { col = sky_color(sc, d); break; }
@@ -930,7 +996,7 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
         if (!cont) { col = A + Pm; break; }
         sA[bounce] = A; sP[bounce] = Pm; sR[bounce] = m.mixR;
         V3 ro, rd;
-        continuation(fr, m, h.pos, h.normal, d, sc.ents[c.ent].kind == 0, c.ent, bounce, (uint32_t)i, 0u, &ro, &rd,
+        continuation(fr, m, h.pos, h.normal, d, (sc.ents[c.ent].kind & ~kEntityMember) == 0, c.ent, bounce, (uint32_t)i, 0u, &ro, &rd,
                      &medium);
         o = ro; d = rd; ++bounce;
     }
@@ -968,11 +1034,15 @@ inline size_t lds_bytes(const DScene& sc) { return sc.lds_mesh >= 0 ? (size_t)sc
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
     const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
     const uint32_t grid = (uint32_t)(chunks < trace_grid() ? chunks : trace_grid());
-    auto k = sc.cull_mode == 0 ? k_wave_primary<0> : sc.cull_mode == 1 ? k_wave_primary<1> : k_wave_primary<2>;
+    auto k = sc.n_groups > 0
+                 ? (sc.cull_mode == 0 ? k_wave_primary<0, true> : sc.cull_mode == 1 ? k_wave_primary<1, true> : k_wave_primary<2, true>)
+                 : (sc.cull_mode == 0 ? k_wave_primary<0, false> : sc.cull_mode == 1 ? k_wave_primary<1, false> : k_wave_primary<2, false>);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, d_ids, d_t);
 }
 void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream) {
-    auto k = sc.cull_mode == 0 ? k_wave_bounce<0> : sc.cull_mode == 1 ? k_wave_bounce<1> : k_wave_bounce<2>;
+    auto k = sc.n_groups > 0
+                 ? (sc.cull_mode == 0 ? k_wave_bounce<0, true> : sc.cull_mode == 1 ? k_wave_bounce<1, true> : k_wave_bounce<2, true>)
+                 : (sc.cull_mode == 0 ? k_wave_bounce<0, false> : sc.cull_mode == 1 ? k_wave_bounce<1, false> : k_wave_bounce<2, false>);
     hipLaunchKernelGGL(k, dim3(trace_grid()), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
 }
 void launch_accumulate(const DWork& wk, const DFrame& fr, void* stream) {
@@ -990,12 +1060,12 @@ void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t
 }
 void launch_trace_rays(const DScene& sc, const double* d_rays, int64_t n, int32_t* ent, int32_t* tri, double* t,
                        double* pos, double* nrm, unsigned long long* stats, void* stream) {
-    hipLaunchKernelGGL(k_trace_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sc, d_rays,
+    hipLaunchKernelGGL(sc.n_groups > 0 ? k_trace_rays<true> : k_trace_rays<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sc, d_rays,
                        n, ent, tri, t, pos, nrm, stats);
 }
 void launch_cast_rays(const DScene& sc, const double* d_rays, int64_t n, uint32_t max_bounce, uint32_t prune,
                       double* color, unsigned long long* stats, void* stream) {
-    hipLaunchKernelGGL(k_cast_rays, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sc, d_rays,
+    hipLaunchKernelGGL(sc.n_groups > 0 ? k_cast_rays<true> : k_cast_rays<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sc, d_rays,
                        n, max_bounce, prune, color, stats);
 }
 void launch_selftest(int op, const double* a, const double* b, int64_t n, double* out, void* stream) {

@@ -110,6 +110,11 @@ class World:
             raise ValueError("verts / normals triangle counts differ")
         return B.check(B.lib.rrt_add_mesh(self.h, _ptr(v), _ptr(n), v.shape[0], mat))
 
+    def add_group(self, members):
+        """Scene::new over entities already added (scene.rs:39-47); returns the group's entity id."""
+        m = np.ascontiguousarray(members, dtype=np.int32)
+        return B.check(B.lib.rrt_add_group(self.h, _ptr(m), m.size))
+
     def add_model(self, path, mat, position, scale):
         return B.check(B.lib.rrt_host_add_model(self.h, path.encode(), mat, _d3(position), _d3(scale)))
 

@@ -149,3 +149,40 @@ def cfg5_scene(b, loaders, n=1000):
     verts, normals = heightfield_mesh(n)
     b.add_mesh(verts, normals, rough)
     return b
+
+
+# ---------------------------------------------------------------------------
+# Scene<T> (src/geometry/scene.rs): entities gathered under a kd-tree over whole entities.
+# ---------------------------------------------------------------------------
+def main_rs_as_scene(b, loaders, skybox="hd_blue_sunset"):
+    """main.rs with its commented-out lines 57-59 enabled instead of 61-63:
+    scene!(SceneType, origin, Model(burger), Sphere(sphere), Sphere(sphere2)) is the world's only
+    entity.  Three members < 5, so the group's tree is a single leaf behind the union box."""
+    main_rs_scene(b, loaders, skybox)
+    b.add_group([0, 1, 2])
+    return b
+
+
+def many_entity_scene(b, loaders, n_spheres=60, seed=7, grouped=True):
+    """A many-entity world (what Scene<T> is for): the UFO, the cube, a seeded cloud of matte,
+    mirror and glass spheres, all under one group; one more sphere stays in the flat entity list."""
+    import numpy as np
+    empty_world(b, loaders, "sky")
+    matte = b.add_material(color_vec(180, 90, 60), 1.0, 0.9, 0.1, 0.3, 20)
+    mirror = b.add_material(color_vec(0, 0, 0), 0.8, 0.0, 1.0, 0.1, 20)
+    glass = b.add_material_ext(color_vec(10, 10, 10), 0.8, 0.05, 0.95, 0.3, 20, LOBE_REFRACT, 1.5)
+    ufo = b.add_material(color_vec(100, 100, 50), 1.0, 1.0, 0.0, 0.3, 20)
+    members = []
+    v, n = loaders.load_model(os.path.join(ASSETS, "obj", "ufo_fix.obj"), (0.0, 30.0, 70.0), (1.0, -1.0, 1.0))
+    members.append(b.add_mesh(v, n, ufo))
+    v, n = loaders.load_model(os.path.join(ASSETS, "obj", "cube.obj"), (-9.0, 2.0, 20.0), (2.0, 2.0, 2.0))
+    members.append(b.add_mesh(v, n, matte))
+    rng = np.random.default_rng(seed)
+    for i in range(n_spheres):
+        c = rng.uniform((-14.0, -8.0, 8.0), (14.0, 8.0, 40.0))
+        r = float(rng.uniform(0.4, 1.6))
+        members.append(b.add_sphere(tuple(float(x) for x in c), r, (matte, mirror, glass)[i % 3]))
+    if grouped:
+        b.add_group(members)
+    b.add_sphere((0.0, -3.0, 6.0), 0.7, mirror)          # stays in world.entities
+    return b
