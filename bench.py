@@ -42,6 +42,9 @@ CONFIGS = {
     "cfg2": ("cfg2_scene", W, H, SPP, 2, "configs[1]"),
     "cfg3": ("cfg3_scene", 1920, 1080, 1, 8, "configs[2]: reflect/refract glass-sphere scene, depth 8, 1920x1080, 1 spp (extension lobes)"),
     "cfg4": ("cfg4_scene", 3840, 2160, 256, 2, "configs[3]: ufo_fix.obj with stochastic diffuse bounces, 3840x2160, 256 spp (extension lobes)"),
+    "cfg2scene": ("cfg2_as_scene", W, H, SPP, 2, "configs[1] with main.rs:57-59 enabled: the three entities under one Scene<T>"),
+    "many": ("many_entity_scene", 1920, 1080, 4, 4, "63 entities (ufo, cube, 60 matte/mirror/glass spheres) under one Scene<T> kd-tree + 1 flat sphere, 1920x1080, 4 spp"),
+    "manyflat": ("many_entity_flat", 1920, 1080, 4, 4, "the same 63 entities in the flat entity list (no Scene<T>), 1920x1080, 4 spp"),
     "cfg5": ("cfg5_scene", 1920, 1080, 64, 2, "configs[4]: synthetic 2M-triangle height field, diffuse bounces, 1920x1080, 64 spp (extension lobes)"),
 }
 

@@ -186,3 +186,12 @@ def many_entity_scene(b, loaders, n_spheres=60, seed=7, grouped=True):
         b.add_group(members)
     b.add_sphere((0.0, -3.0, 6.0), 0.7, mirror)          # stays in world.entities
     return b
+
+
+def cfg2_as_scene(b, loaders):
+    """cfg2's world with the three entities under one Scene<T> (bench: cost of the union-box gate)."""
+    return main_rs_as_scene(b, loaders, skybox="blue_sunset")
+
+
+def many_entity_flat(b, loaders):
+    return many_entity_scene(b, loaders, grouped=False)
