@@ -17,6 +17,19 @@ namespace rrt {
 
 thread_local std::string g_host_err;
 
+static int hfail(int code, const std::string& m);
+// no C++ exception crosses the C ABI (see rrt_api.cpp)
+static int host_on_exception() {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        return hfail(RRT_E_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return hfail(RRT_E_STATE, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return hfail(RRT_E_STATE, "internal error");
+    }
+}
 static int hfail(int code, const std::string& m) {
     g_host_err = m;
     set_last_error(m);
@@ -316,7 +329,7 @@ int save_png_rgb8(const char* path, const uint8_t* rgb, uint32_t w, uint32_t h) 
 extern "C" {
 
 int rrt_host_load_model(const char* obj_path, const double position[3], const double scale[3], double** verts,
-                        double** normals, int64_t* n_triangles) {
+                        double** normals, int64_t* n_triangles) try {
     if (!obj_path || !position || !scale || !verts || !normals || !n_triangles) return rrt::hfail(RRT_E_INVALID, "null argument");
     std::vector<double> v, n;
     const int rc = rrt::load_model(obj_path, position, scale, &v, &n);
@@ -328,17 +341,21 @@ int rrt_host_load_model(const char* obj_path, const double position[3], const do
     std::memcpy(*verts, v.data(), v.size() * sizeof(double));
     std::memcpy(*normals, n.data(), n.size() * sizeof(double));
     return RRT_OK;
+} catch (...) {
+    return rrt::host_on_exception();
 }
 
-int rrt_host_add_model(rrt_scene* s, const char* obj_path, int material, const double position[3], const double scale[3]) {
+int rrt_host_add_model(rrt_scene* s, const char* obj_path, int material, const double position[3], const double scale[3]) try {
     if (!s || !obj_path || !position || !scale) return rrt::hfail(RRT_E_INVALID, "null argument");
     std::vector<double> v, n;
     const int rc = rrt::load_model(obj_path, position, scale, &v, &n);
     if (rc) return rc;
     return rrt_add_mesh(s, v.data(), n.data(), (int64_t)(n.size() / 3), material);
+} catch (...) {
+    return rrt::host_on_exception();
 }
 
-int rrt_host_load_png_rgb8(const char* path, uint8_t** rgb8, uint32_t* w, uint32_t* h) {
+int rrt_host_load_png_rgb8(const char* path, uint8_t** rgb8, uint32_t* w, uint32_t* h) try {
     if (!path || !rgb8 || !w || !h) return rrt::hfail(RRT_E_INVALID, "null argument");
     std::vector<uint8_t> px;
     const int rc = rrt::load_png_rgb8(path, &px, w, h);
@@ -347,14 +364,18 @@ int rrt_host_load_png_rgb8(const char* path, uint8_t** rgb8, uint32_t* w, uint32
     if (!*rgb8) return rrt::hfail(RRT_E_NOMEM, "out of host memory");
     std::memcpy(*rgb8, px.data(), px.size());
     return RRT_OK;
+} catch (...) {
+    return rrt::host_on_exception();
 }
 
-int rrt_host_save_png_rgb8(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h) {
+int rrt_host_save_png_rgb8(const char* path, const uint8_t* rgb8, uint32_t w, uint32_t h) try {
     if (!path) return rrt::hfail(RRT_E_INVALID, "null path");
     return rrt::save_png_rgb8(path, rgb8, w, h);
+} catch (...) {
+    return rrt::host_on_exception();
 }
 
-int rrt_host_load_cubemap(rrt_scene* s, const char* folder) {
+int rrt_host_load_cubemap(rrt_scene* s, const char* folder) try {
     if (!s || !folder) return rrt::hfail(RRT_E_INVALID, "null argument");
     // maps = [left, right, down, up, front, back]   (cubemap.rs:47-48)
     static const char* names[6] = {"left", "right", "down", "up", "front", "back"};
@@ -368,6 +389,8 @@ int rrt_host_load_cubemap(rrt_scene* s, const char* folder) {
         if (rc) return rc;
     }
     return RRT_OK;
+} catch (...) {
+    return rrt::host_on_exception();
 }
 
 void rrt_host_free(void* p) { std::free(p); }

@@ -24,6 +24,20 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 
+// No C++ exception may cross the C ABI (the caller may be Rust, C or ctypes): every entry point that
+// can allocate is a function-try-block ending here.
+int on_exception() {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        return fail(RRT_E_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(RRT_E_STATE, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(RRT_E_STATE, "internal error");
+    }
+}
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -555,7 +569,7 @@ int rrt_add_material_ext(rrt_scene* s, const double color[3], double albedo, dou
 }
 
 int rrt_add_material(rrt_scene* s, const double color[3], double albedo, double lambert_mix, double reflective_mix,
-                     double phong_mix, int32_t alpha) {
+                     double phong_mix, int32_t alpha) try {
     if (!s || !color) return fail(RRT_E_INVALID, "null argument");
     rrt::DMaterial m{};
     m.lobe = 0;
@@ -569,9 +583,11 @@ int rrt_add_material(rrt_scene* s, const double color[3], double albedo, double 
     s->mats.push_back(m);
     s->dirty = true;
     return (int)s->mats.size() - 1;
+} catch (...) {
+    return on_exception();
 }
 
-int rrt_add_sphere(rrt_scene* s, const double center[3], double radius, int material) {
+int rrt_add_sphere(rrt_scene* s, const double center[3], double radius, int material) try {
     if (!s || !center) return fail(RRT_E_INVALID, "null argument");
     if (material < 0 || material >= (int)s->mats.size()) return fail(RRT_E_INVALID, "unknown material id");
     rrt::DSphere sp{};
@@ -583,9 +599,11 @@ int rrt_add_sphere(rrt_scene* s, const double center[3], double radius, int mate
     s->ents.push_back(rrt::DEntity{0, (int32_t)s->spheres.size() - 1});
     s->dirty = true;
     return (int)s->ents.size() - 1;
+} catch (...) {
+    return on_exception();
 }
 
-int rrt_add_mesh(rrt_scene* s, const double* verts, const double* normals, int64_t n, int material) {
+int rrt_add_mesh(rrt_scene* s, const double* verts, const double* normals, int64_t n, int material) try {
     if (!s || !verts || !normals) return fail(RRT_E_INVALID, "null argument");
     if (n <= 0 || n > 0x3fffffff) return fail(RRT_E_INVALID, "triangle count out of range");
     if (material < 0 || material >= (int)s->mats.size()) return fail(RRT_E_INVALID, "unknown material id");
@@ -607,9 +625,11 @@ int rrt_add_mesh(rrt_scene* s, const double* verts, const double* normals, int64
     s->ents.push_back(rrt::DEntity{1, (int32_t)s->meshes.size() - 1});
     s->dirty = true;
     return (int)s->ents.size() - 1;
+} catch (...) {
+    return on_exception();
 }
 
-int rrt_add_group(rrt_scene* s, const int32_t* members, int32_t n) {
+int rrt_add_group(rrt_scene* s, const int32_t* members, int32_t n) try {
     if (!s || !members) return fail(RRT_E_INVALID, "null argument");
     if (n <= 0) return fail(RRT_E_INVALID, "a group needs at least one member");
     auto g = std::make_unique<HostGroup>();
@@ -643,9 +663,11 @@ int rrt_add_group(rrt_scene* s, const int32_t* members, int32_t n) {
     s->ents.push_back(rrt::DEntity{2, (int32_t)s->groups.size() - 1});
     s->dirty = true;
     return (int)s->ents.size() - 1;
+} catch (...) {
+    return on_exception();
 }
 
-int rrt_set_sky_face(rrt_scene* s, int face, const uint8_t* rgb8, uint32_t w, uint32_t h) {
+int rrt_set_sky_face(rrt_scene* s, int face, const uint8_t* rgb8, uint32_t w, uint32_t h) try {
     if (!s || !rgb8) return fail(RRT_E_INVALID, "null argument");
     if (face < 0 || face > 5 || w == 0 || h == 0) return fail(RRT_E_INVALID, "bad face index or size");
     s->sky[face].rgb.assign(rgb8, rgb8 + (size_t)w * h * 3);
@@ -653,6 +675,8 @@ int rrt_set_sky_face(rrt_scene* s, int face, const uint8_t* rgb8, uint32_t w, ui
     s->sky[face].h = h;
     s->dirty = true;
     return RRT_OK;
+} catch (...) {
+    return on_exception();
 }
 
 int rrt_set_directional_light(rrt_scene* s, const double direction[3], const double color[3], double intensity) {
@@ -690,9 +714,11 @@ int rrt_set_cull_mode(rrt_scene* s, int mode) {
     return RRT_OK;
 }
 
-int rrt_scene_commit(rrt_scene* s) {
+int rrt_scene_commit(rrt_scene* s) try {
     if (!s) return fail(RRT_E_INVALID, "null scene");
     return commit(s);
+} catch (...) {
+    return on_exception();
 }
 
 int64_t rrt_tile_slots(uint32_t width, uint32_t height, uint32_t tile_world) {
@@ -702,12 +728,14 @@ int64_t rrt_tile_slots(uint32_t width, uint32_t height, uint32_t tile_world) {
 }
 
 int rrt_render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids, void* d_t,
-                      void* d_color, void* stream) {
+                      void* d_color, void* stream) try {
     return render_device(s, cam, st, d_rgb8, d_ids, d_t, d_color, stream);
+} catch (...) {
+    return on_exception();
 }
 
 int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint8_t* out_rgb8, int32_t* out_ids,
-               double* out_t, double* out_color) {
+               double* out_t, double* out_color) try {
     if (!s || !st) return fail(RRT_E_INVALID, "null argument");
     if (st->tile_world != 1) return fail(RRT_E_INVALID, "rrt_render needs tile_world == 1");
     HIP_TRY(hipSetDevice(s->device));
@@ -725,6 +753,8 @@ int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint
     if (out_t) HIP_TRY(hipMemcpy(out_t, s->w_t.p, npx * 8, hipMemcpyDeviceToHost));
     if (out_color) HIP_TRY(hipMemcpy(out_color, s->w_color.p, npx * 24, hipMemcpyDeviceToHost));
     return RRT_OK;
+} catch (...) {
+    return on_exception();
 }
 
 int rrt_assemble_tiles(const void* d_gathered, uint32_t width, uint32_t height, uint32_t tile_world, void* d_rgb8,
@@ -774,17 +804,21 @@ static int ray_query(rrt_scene* s, const double* rays, int64_t n, bool cast, uin
 }
 
 int rrt_trace_rays(rrt_scene* s, const double* rays, int64_t n, int32_t* ent, int32_t* tri, double* t, double* pos,
-                   double* normal) {
+                   double* normal) try {
     return ray_query(s, rays, n, false, 0, 0, ent, tri, t, pos, normal, nullptr);
+} catch (...) {
+    return on_exception();
 }
 
 int rrt_cast_rays(rrt_scene* s, const double* rays, int64_t n, uint32_t max_bounce, uint32_t prune_zero_mix,
-                  double* color) {
+                  double* color) try {
     if (!color) return fail(RRT_E_INVALID, "null colour output");
     return ray_query(s, rays, n, true, max_bounce, prune_zero_mix, nullptr, nullptr, nullptr, nullptr, nullptr, color);
+} catch (...) {
+    return on_exception();
 }
 
-int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) {
+int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) try {
     rrt_scene* s = const_cast<rrt_scene*>(cs);
     if (!s || !out) return fail(RRT_E_INVALID, "null argument");
     if (!s->have_frame) return fail(RRT_E_STATE, "no frame rendered yet");
@@ -814,6 +848,8 @@ int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) {
     for (int l = 1; l < 4; ++l) s->stats.level_rays[l] = dev[4 + l];
     *out = s->stats;
     return RRT_OK;
+} catch (...) {
+    return on_exception();
 }
 
 // the tree of a mesh (over its triangles) or of a group (over its members, numbered in the order given)
