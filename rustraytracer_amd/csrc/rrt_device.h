@@ -131,11 +131,12 @@ struct DScene {
     int32_t lds_mesh;        // mesh whose DNodeI array the trace kernels stage in LDS, or -1
     int32_t lds_nodes;       // its node count (LDS bytes = 16 * lds_nodes)
     int32_t cull_mode;       // 0 = off, 1 = on, 2 = verify (run both, count cull-vs-exact disagreements)
-    int32_t pad0;
+    int32_t lds_ents;        // 1: the trace kernels keep the entity table in LDS (n_ents <= kMaxLdsEnts)
 };
 
 constexpr int32_t kGroup = 4;            // a leaf's run in the stream starts at a multiple of kGroup and is padded to one
 constexpr int32_t kStreamPad = 4;        // readable entries past the end of DMesh::tris / DMesh::grp
+constexpr int32_t kMaxLdsEnts = 64;      // 128 B of LDS per entity
 constexpr int32_t kMaxLdsNodes = 3072;   // 48 KB of LDS per 256-thread block at most
 
 // Ray queue, SoA.  cap entries each.

@@ -463,12 +463,12 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, Leaf
 
 // Sphere::collide (sphere.rs:28-47): the hit parameter only; position and normal are rebuilt by
 // finish_hit for the entity that wins.
-RRT_DEV bool sphere_collide(const DSphere* __restrict__ S, V3 o, V3 d, double* tout) {
-    const V3 l = ld3(S->c) - o;
+RRT_DEV bool sphere_collide(const DSphere& S, V3 o, V3 d, double* tout) {
+    const V3 l = ld3(S.c) - o;
     const double tca = dot(l, d);
     if (tca < 0.0) return false;
     const double d2 = mag2(l) - tca * tca;
-    const double r2 = S->r2;
+    const double r2 = S.r2;
     if (d2 > r2) return false;
     const double thc = sqrt(r2 - d2);
     *tout = tca - thc;
@@ -477,11 +477,11 @@ RRT_DEV bool sphere_collide(const DSphere* __restrict__ S, V3 o, V3 d, double* t
 
 // EXTENSION: the sphere the ray travels inside (entered through a Refraction lobe) answers with
 // its far root; sphere.rs:28-47 only ever returns the near one.
-RRT_DEV bool sphere_collide_inside(const DSphere* __restrict__ S, V3 o, V3 d, double* tout) {
-    const V3 l = ld3(S->c) - o;
+RRT_DEV bool sphere_collide_inside(const DSphere& S, V3 o, V3 d, double* tout) {
+    const V3 l = ld3(S.c) - o;
     const double tca = dot(l, d);
     const double d2 = mag2(l) - tca * tca;
-    const double r2 = S->r2;
+    const double r2 = S.r2;
     if (d2 > r2) return false;
     const double thc = sqrt(r2 - d2);
     const double t = tca + thc;
@@ -496,23 +496,49 @@ struct Closest {
     int32_t entry;   // mesh: winning stream entry
 };
 
+// What a trace block keeps in LDS (stage_scene): the descent array of one mesh, and the world's
+// entity table -- one kEntRec-dword record per entity: kind, index, then the DSphere / DMesh /
+// DGroup it refers to.  Read from global memory these are two dependent scalar loads per entity and
+// ray (entity -> sphere/mesh struct), ~600 cycles a wave cannot overlap with anything: 0.1 ms per
+// entity on a 1080p/16spp frame.  The records are wave-uniform, so they go back into SGPRs.
+#define RRT_LDS __attribute__((address_space(3)))
+constexpr int32_t kEntRec = 32;
+static_assert(sizeof(DSphere) <= 4 * (kEntRec - 2) && sizeof(DMesh) <= 4 * (kEntRec - 2) && sizeof(DGroup) <= 4 * (kEntRec - 2),
+              "entity record too small");
+struct Staged {
+    const DNodeI* nodes;             // descent array of scene.lds_mesh, or nullptr
+    const RRT_LDS uint32_t* ents;    // entity records, or nullptr (then everything is read from global memory)
+};
+
+template <class T>
+RRT_DEV T lds_uniform(const RRT_LDS uint32_t* p) {
+    static_assert(sizeof(T) % 4 == 0, "dword-sized structs only");
+    uint32_t w[sizeof(T) / 4];
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(T) / 4; ++i) w[i] = __builtin_amdgcn_readfirstlane(p[i]);
+    T t;
+    __builtin_memcpy(&t, w, sizeof(T));
+    return t;
+}
+
 // Entity::collide of a sphere or a mesh + the "closer than what we have" update that both the world
 // loop (tracer.rs:183-188) and a kd leaf over entities (kdtree.rs:204-211) apply: strict <, so the
 // first of equals stays.
+// `rec` != nullptr: entity e's LDS record (e is wave-uniform then); nullptr: read from global memory.
 template <int CULL>
-RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, int32_t e, DEntity ent, V3 o, V3 d, int32_t medium,
-                            Closest* best, unsigned long long* stats) {
+RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LDS uint32_t* rec, int32_t e, DEntity ent,
+                            V3 o, V3 d, int32_t medium, Closest* best, unsigned long long* stats) {
     if (ent.kind == 0) {
         double t;
-        const bool got = (e == medium) ? sphere_collide_inside(sc.spheres + ent.index, o, d, &t)
-                                       : sphere_collide(sc.spheres + ent.index, o, d, &t);
+        const DSphere S = rec ? lds_uniform<DSphere>(rec + 2) : sc.spheres[ent.index];
+        const bool got = (e == medium) ? sphere_collide_inside(S, o, d, &t) : sphere_collide(S, o, d, &t);
         if (got) {
             const V3 pos = o + d * t;                  // sphere.rs:39
             const double dist = mag2(pos - o);         // tracer.rs:184
             if (dist < best->dist) { best->dist = dist; best->t = t; best->ent = e; best->entry = -1; }
         }
     } else {
-        const DMesh M = sc.meshes[ent.index];
+        const DMesh M = rec ? lds_uniform<DMesh>(rec + 2) : sc.meshes[ent.index];
         LeafBest h;
         mesh_collide<CULL>(M, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, &h, stats);
         // same |pos - origin|^2 as the leaf-level metric (kdtree.rs:206 == tracer.rs:184)
@@ -550,7 +576,7 @@ RRT_DEV void group_collide(const DScene& sc, const DGroup& G, const DNodeI* lnod
             const int32_t e = members[lr.first + k];
             DEntity ent = sc.ents[e];
             ent.kind &= ~kEntityMember;            // 0 sphere or 1 mesh (rrt_add_group admits nothing else)
-            entity_collide<CULL>(sc, lnodes, e, ent, o, d, medium, &best, stats);
+            entity_collide<CULL>(sc, lnodes, nullptr, e, ent, o, d, medium, &best, stats);   // e differs per lane
         }
         if (best.ent >= 0) {
             *out = best;
@@ -568,22 +594,24 @@ RRT_DEV void group_collide(const DScene& sc, const DGroup& G, const DNodeI* lnod
 // The entity loop of RayTracer::cast (tracer.rs:178-190).  GROUPS: the scene holds Scene<T>
 // entities (kind 2); their members carry kEntityMember and are not in world.entities.
 template <int CULL, bool GROUPS>
-RRT_DEV void closest_hit(const DScene& sc, const DNodeI* lnodes, V3 o, V3 d, int32_t medium, Closest* best,
+RRT_DEV void closest_hit(const DScene& sc, Staged lds, V3 o, V3 d, int32_t medium, Closest* best,
                          unsigned long long* stats) {
+    const DNodeI* lnodes = lds.nodes;
     best->dist = kF64Max; best->t = 0.0; best->ent = -1; best->entry = -1;
     for (int32_t e = 0; e < sc.n_ents; ++e) {
-        DEntity ent = sc.ents[e];
+        const RRT_LDS uint32_t* rec = lds.ents ? lds.ents + e * kEntRec : nullptr;
+        const DEntity ent = rec ? lds_uniform<DEntity>(rec) : sc.ents[e];
         if (GROUPS) {
             if (ent.kind & kEntityMember) continue;
             if (ent.kind == 2) {
-                const DGroup G = sc.groups[ent.index];
+                const DGroup G = rec ? lds_uniform<DGroup>(rec + 2) : sc.groups[ent.index];
                 Closest h;
                 group_collide<CULL>(sc, G, lnodes, o, d, medium, &h, stats);
                 if (h.ent >= 0 && h.dist < best->dist) *best = h;
                 continue;
             }
         }
-        entity_collide<CULL>(sc, lnodes, e, ent, o, d, medium, best, stats);
+        entity_collide<CULL>(sc, lnodes, rec, e, ent, o, d, medium, best, stats);
     }
 }
 
@@ -766,7 +794,7 @@ RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y
 
 // One cast() (tracer.rs:177-211) of path `path` at depth `bounce`.
 template <bool PRIMARY, int CULL, bool GROUPS>
-RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk, const DFrame& fr, bool active,
+RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DFrame& fr, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
                          uint32_t pixel, uint32_t sample) {
     const uint64_t P = wk.cap;
@@ -776,7 +804,7 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
     if (active) {
         Closest c;
         CNT(0);
-        closest_hit<CULL, GROUPS>(sc, lnodes, o, d, medium, &c, wk.stats);
+        closest_hit<CULL, GROUPS>(sc, lds, o, d, medium, &c, wk.stats);
         Hit h;
         finish_hit(sc, o, d, c, &h);
         const int32_t ent = c.ent;
@@ -828,16 +856,39 @@ RRT_DEV void process_ray(const DScene& sc, const DNodeI* lnodes, const DWork& wk
     }
 }
 
-// Copies the descent array of scene.lds_mesh into LDS (all threads of the block; ends with a barrier).
-// Returns the LDS pointer, or nullptr when nothing is staged.
-RRT_DEV const DNodeI* stage_nodes(const DScene& sc, unsigned char* smem) {
-    if (sc.lds_mesh < 0) return nullptr;
-    const DMesh M = sc.meshes[sc.lds_mesh];
-    const RRT_GLOBAL double* src = (const RRT_GLOBAL double*)M.nodes;   // 16 B = 2 doubles per node
-    double* dst = (double*)smem;
-    for (int32_t i = threadIdx.x; i < 2 * sc.lds_nodes; i += blockDim.x) dst[i] = src[i];
+// Fills the block's LDS (all threads; ends with a barrier): the descent array of scene.lds_mesh and,
+// after it, the entity records.  Either part may be absent (see DScene::lds_mesh / lds_ents).
+RRT_DEV Staged stage_scene(const DScene& sc, unsigned char* smem) {
+    Staged st{nullptr, nullptr};
+    uint32_t off = 0;
+    if (sc.lds_mesh >= 0) {
+        const DMesh M = sc.meshes[sc.lds_mesh];
+        const RRT_GLOBAL double* src = (const RRT_GLOBAL double*)M.nodes;   // 16 B = 2 doubles per node
+        double* dst = (double*)smem;
+        for (int32_t i = threadIdx.x; i < 2 * sc.lds_nodes; i += blockDim.x) dst[i] = src[i];
+        st.nodes = (const DNodeI*)smem;
+        off = (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI);
+    }
+    if (sc.lds_ents) {
+        RRT_LDS uint32_t* tab = (RRT_LDS uint32_t*)(smem + off);
+        for (int32_t i = threadIdx.x; i < sc.n_ents * kEntRec; i += blockDim.x) {
+            const int32_t e = i / kEntRec, w = i % kEntRec;
+            const DEntity ent = sc.ents[e];
+            const int32_t kind = ent.kind & ~kEntityMember;
+            const uint32_t* src = kind == 0   ? (const uint32_t*)(sc.spheres + ent.index)
+                                  : kind == 1 ? (const uint32_t*)(sc.meshes + ent.index)
+                                              : (const uint32_t*)(sc.groups + ent.index);
+            const int32_t n = kind == 0 ? (int32_t)sizeof(DSphere) / 4 : kind == 1 ? (int32_t)sizeof(DMesh) / 4 : (int32_t)sizeof(DGroup) / 4;
+            uint32_t v = 0u;
+            if (w == 0) v = (uint32_t)ent.kind;
+            else if (w == 1) v = (uint32_t)ent.index;
+            else if (w - 2 < n) v = src[w - 2];
+            tab[i] = v;
+        }
+        st.ents = tab;
+    }
     __syncthreads();
-    return (const DNodeI*)smem;
+    return st;
 }
 
 // Persistent blocks: block b takes path tiles b, b + grid, ... (neighbouring tiles, which cost
@@ -845,7 +896,7 @@ RRT_DEV const DNodeI* stage_nodes(const DScene& sc, unsigned char* smem) {
 template <int CULL, bool GROUPS>
 __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const DNodeI* lnodes = stage_nodes(sc, smem);
+    const Staged lds = stage_scene(sc, smem);
     const uint32_t n_chunks = (uint32_t)(((uint64_t)fr.ns * fr.npx_local) >> 8);   // 256 paths per chunk, exact
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
         const uint32_t path = chunk * 256u + threadIdx.x;
@@ -855,7 +906,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         const uint32_t sample = fr.s0 + s_local;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         if (active) primary_ray(fr, x, y, sample, &o, &d);
-        process_ray<true, CULL, GROUPS>(sc, lnodes, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample);
+        process_ray<true, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample);
     }
 }
 
@@ -868,7 +919,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
         if (blockIdx.x == 0 && threadIdx.x == 0 && bounce < 4u) atomicAdd(&wk.stats[4 + bounce], 0ull);
         return;
     }
-    const DNodeI* lnodes = stage_nodes(sc, smem);
+    const Staged lds = stage_scene(sc, smem);
     const uint64_t P = wk.cap;
     const DQueue& q = wk.q[bounce & 1];
     // every lane of a wave runs the same number of iterations (queue_slot uses wave-wide ops)
@@ -891,7 +942,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
             pixel = y * fr.width + x;
             sample = fr.s0 + s_local;
         }
-        process_ray<false, CULL, GROUPS>(sc, lnodes, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, pixel, sample);
+        process_ray<false, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, pixel, sample);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&wk.stats[0], (unsigned long long)count);
@@ -956,9 +1007,9 @@ __global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* ray
     if (i >= n) return;
     const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
     Closest c;
-    if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, nullptr, o, d, -1, &c, stats);
-    else if (sc.cull_mode == 1) closest_hit<1, GROUPS>(sc, nullptr, o, d, -1, &c, stats);
-    else closest_hit<2, GROUPS>(sc, nullptr, o, d, -1, &c, stats);
+    if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, Staged{nullptr, nullptr}, o, d, -1, &c, stats);
+    else if (sc.cull_mode == 1) closest_hit<1, GROUPS>(sc, Staged{nullptr, nullptr}, o, d, -1, &c, stats);
+    else closest_hit<2, GROUPS>(sc, Staged{nullptr, nullptr}, o, d, -1, &c, stats);
     Hit h;
     finish_hit(sc, o, d, c, &h);
     const int32_t e = c.ent;
@@ -984,8 +1035,8 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
     V3 col;
     for (;;) {
         Closest c;
-        if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, nullptr, o, d, medium, &c, stats);
-        else closest_hit<2, GROUPS>(sc, nullptr, o, d, medium, &c, stats);
+        if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, Staged{nullptr, nullptr}, o, d, medium, &c, stats);
+        else closest_hit<2, GROUPS>(sc, Staged{nullptr, nullptr}, o, d, medium, &c, stats);
         Hit h;
         finish_hit(sc, o, d, c, &h);
         if (!h.hit) { col = sky_color(sc, d); break; }
@@ -1027,7 +1078,9 @@ inline uint32_t trace_grid() {
     }();
     return g;
 }
-inline size_t lds_bytes(const DScene& sc) { return sc.lds_mesh >= 0 ? (size_t)sc.lds_nodes * sizeof(DNodeI) : 0; }
+inline size_t lds_bytes(const DScene& sc) {
+    return (sc.lds_mesh >= 0 ? (size_t)sc.lds_nodes * sizeof(DNodeI) : 0) + (sc.lds_ents ? (size_t)sc.n_ents * kEntRec * 4 : 0);
+}
 
 }  // namespace
 

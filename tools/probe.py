@@ -25,3 +25,13 @@ m3 = c.add_material(scenes.color_vec(100, 100, 50), 1.0, 1.0, 0.0, 0.3, 20)
 v, n = H.loaders.load_model(os.path.join(scenes.ASSETS, "obj", "ufo_fix.obj"), (0.0, 30.0, 70.0), (1.0, -1.0, 1.0))
 c.add_mesh(v, n, m3); run("sky + ufo", c)
 d = scenes.cfg2_scene(H.World(device=0), H.loaders); run("cfg2", d)
+e = H.World(device=0); scenes.empty_world(e, H.loaders, "blue_sunset")
+m1 = e.add_material(scenes.color_vec(100, 100, 200), 0.8, 1.0, 0.01, 0.1, 20)
+e.add_sphere((-3.0, 0.0, -50.0), 1.0, m1); e.add_sphere((2.0, 0.0, -80.0), 1.0, m1); run("2 spheres behind the camera", e)
+f = H.World(device=0); scenes.empty_world(f, H.loaders, "blue_sunset")
+m1 = f.add_material(scenes.color_vec(100, 100, 200), 0.8, 1.0, 0.01, 0.1, 20)
+f.add_sphere((-3.0, 0.0, 5.0), 1.0, m1); run("1 matte sphere (mixR 0.01)", f)
+g = H.World(device=0); scenes.empty_world(g, H.loaders, "blue_sunset")
+v, n = H.loaders.load_model(os.path.join(scenes.ASSETS, "obj", "ufo_fix.obj"), (0.0, 30.0, -170.0), (1.0, -1.0, 1.0))
+m3 = g.add_material(scenes.color_vec(100, 100, 50), 1.0, 1.0, 0.0, 0.3, 20)
+g.add_mesh(v, n, m3); run("ufo behind the camera", g)
