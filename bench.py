@@ -244,6 +244,12 @@ def main():
                         roof["traffic_source"] = t.get("source")
                 except (ValueError, KeyError):
                     pass
+            vf = os.path.join(ROOT, "profiles", "valu_busy.json")
+            if os.path.exists(vf):       # SQ_ACTIVE_INST_VALU over the launch's SIMD-cycles (tools/valu_busy.py)
+                try:
+                    roof["valu_issue"] = json.load(open(vf)).get("k_wave_primary")
+                except ValueError:
+                    pass
             if prim_c:
                 n = float(n_prim)
                 per = {k: prim_c[k] / n for k in ("node_steps", "leaf_visits", "tri_tests", "sphere_tests", "box_tests")}

@@ -6,6 +6,7 @@ cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
 cp gpurun_out/${TAG}_kernel_stats.csv profiles/${TAG}_kernel_stats.csv
 cp gpurun_out/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
 cp gpurun_out/${TAG}_sq_summary.txt profiles/${TAG}_sq_summary.txt
+python3 tools/valu_busy.py gpurun_out/sq_$TAG profiles/${TAG}_kernel_stats.csv > profiles/valu_busy.json
 for C in FETCH_SIZE WRITE_SIZE; do
   f=$(find gpurun_out/pmc_$TAG/$C -name "*counter_collection.csv" | head -1)
   python3 - "$f" profiles/${TAG}_pmc_$C.csv <<'PY'
