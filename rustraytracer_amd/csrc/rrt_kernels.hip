@@ -856,6 +856,13 @@ RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DF
     }
 }
 
+// Bytes of LDS stage_scene fills (descent array, then entity records); the bounce kernel's unit
+// counter sits right behind them.
+__host__ __device__ inline uint32_t lds_layout_bytes(const DScene& sc) {
+    return (sc.lds_mesh >= 0 ? (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI) : 0u) +
+           (sc.lds_ents ? (uint32_t)sc.n_ents * (uint32_t)kEntRec * 4u : 0u);
+}
+
 // Fills the block's LDS (all threads; ends with a barrier): the descent array of scene.lds_mesh and,
 // after it, the entity records.  Either part may be absent (see DScene::lds_mesh / lds_ents).
 RRT_DEV Staged stage_scene(const DScene& sc, unsigned char* smem) {
@@ -910,22 +917,34 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
     }
 }
 
+// Bounce level `bounce`: the queue is cut into units of 64 rays; block b owns units b, b + grid, ...
+// and its four waves pull them from a counter in LDS.  Rays of a bounce level differ in cost by
+// more than an order of magnitude (a reflection that leaves the UFO at once vs. one that walks a
+// dozen leaves inside it); with one fixed 64-ray slice per wave and round, a block kept its LDS and
+// register slots until its slowest wave was done (measured: 2.4 of 4 waves/SIMD resident).
 template <int CULL, bool GROUPS>
 __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = wk.q_count[bounce];
-    const uint32_t stride = gridDim.x * 256u;
-    if (blockIdx.x * 256u >= count) {          // whole block idle (block-uniform): skip the staging too
-        if (blockIdx.x == 0 && threadIdx.x == 0 && bounce < 4u) atomicAdd(&wk.stats[4 + bounce], 0ull);
-        return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&wk.stats[0], (unsigned long long)count);
+        if (bounce < 4u) atomicAdd(&wk.stats[4 + bounce], (unsigned long long)count);
     }
-    const Staged lds = stage_scene(sc, smem);
+    const uint32_t n_units = (count + 63u) >> 6;
+    if (blockIdx.x >= n_units) return;          // whole block idle (block-uniform): skip the staging too
+    const uint32_t my_units = (n_units - blockIdx.x + gridDim.x - 1u) / gridDim.x;
+    RRT_LDS uint32_t* next_unit = (RRT_LDS uint32_t*)(smem + lds_layout_bytes(sc));
+    if (threadIdx.x == 0) *next_unit = 0u;
+    const Staged lds = stage_scene(sc, smem);   // ends with the barrier that also publishes *next_unit
     const uint64_t P = wk.cap;
     const DQueue& q = wk.q[bounce & 1];
-    // every lane of a wave runs the same number of iterations (queue_slot uses wave-wide ops)
-    const uint32_t rounds = (count + stride - 1) / stride;
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    for (uint32_t r = 0; r < rounds; ++r, i += stride) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (;;) {
+        uint32_t u = 0u;
+        if (lane == 0u) u = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+        if (u >= my_units) break;               // wave-uniform; the counter only grows, so every wave gets here
+        const uint32_t i = (u * gridDim.x + blockIdx.x) * 64u + lane;
         const bool active = i < count;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         uint32_t path = 0, pixel = 0, sample = 0;
@@ -943,10 +962,6 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
             sample = fr.s0 + s_local;
         }
         process_ray<false, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, pixel, sample);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&wk.stats[0], (unsigned long long)count);
-        if (bounce < 4u) atomicAdd(&wk.stats[4 + bounce], (unsigned long long)count);
     }
 }
 
@@ -1078,9 +1093,15 @@ inline uint32_t trace_grid() {
     }();
     return g;
 }
-inline size_t lds_bytes(const DScene& sc) {
-    return (sc.lds_mesh >= 0 ? (size_t)sc.lds_nodes * sizeof(DNodeI) : 0) + (sc.lds_ents ? (size_t)sc.n_ents * kEntRec * 4 : 0);
+inline uint32_t bounce_grid() {
+    static const uint32_t g = [] {
+        const char* e = getenv("RRT_BOUNCE_GRID");
+        const long v = e ? atol(e) : 0;
+        return (uint32_t)(v > 0 && v <= 65535 ? v : 256 * 8);   // measured: 1024-3072 blocks within 1 %, 512 and 8192 slower
+    }();
+    return g;
 }
+inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) + 16; }   // + the bounce kernel's unit counter
 
 }  // namespace
 
@@ -1096,7 +1117,7 @@ void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t
     auto k = sc.n_groups > 0
                  ? (sc.cull_mode == 0 ? k_wave_bounce<0, true> : sc.cull_mode == 1 ? k_wave_bounce<1, true> : k_wave_bounce<2, true>)
                  : (sc.cull_mode == 0 ? k_wave_bounce<0, false> : sc.cull_mode == 1 ? k_wave_bounce<1, false> : k_wave_bounce<2, false>);
-    hipLaunchKernelGGL(k, dim3(trace_grid()), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
+    hipLaunchKernelGGL(k, dim3(bounce_grid()), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
 }
 void launch_accumulate(const DWork& wk, const DFrame& fr, void* stream) {
     hipLaunchKernelGGL(k_accumulate, dim3(fr.npx_local / 256), dim3(256), 0, (hipStream_t)stream, wk, fr);
