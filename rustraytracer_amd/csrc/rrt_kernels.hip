@@ -813,6 +813,7 @@ RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DF
             if (d_t) d_t[pixel] = h.hit ? h.t : 0.0;
         }
         V3 col;
+        uint32_t fold_from = bounce;        // records [0, fold_from) still enclose col
         if (h.hit) {
             const DMaterial m = sc.mats[h.mat];
             V3 A, Pm;
@@ -829,14 +830,27 @@ RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DF
             } else {
                 col = A + Pm;   // Reflection returned None (reflection.rs:26-28) or was pruned
             }
-        } else {
+        } else if (PRIMARY) {
             CNT(8);
             col = sky_color(sc, d);
+        } else {
+            // A bounce ray that leaves the scene ends its path (most do).  Its innermost enclosing
+            // record is requested BEFORE the sky texel: both are HBM misses on incoherent addresses,
+            // and the bounce kernel lives on memory latency (22 % VALU-busy), so they should overlap.
+            CNT(8);
+            const uint32_t k = bounce - 1u;
+            const size_t r = (size_t)k * 3 * P + path;
+            const double mr = wk.recR[(size_t)k * P + path];
+            const V3 A = mk(wk.recA[r], wk.recA[r + P], wk.recA[r + 2 * P]);
+            const V3 Pm = mk(wk.recP[r], wk.recP[r + P], wk.recP[r + 2 * P]);
+            col = sky_color(sc, d);
+            col = (A + col * mr) + Pm;
+            fold_from = k;
         }
         if (!cont) {
             CNT(10);
             // fold the enclosing casts: final = (A + R*mixR) + Pm  (tracer.rs:194-202)
-            for (uint32_t k = bounce; k-- > 0;) {
+            for (uint32_t k = fold_from; k-- > 0;) {
                 const size_t r = (size_t)k * 3 * P + path;
                 const double mr = wk.recR[(size_t)k * P + path];
                 const V3 A = mk(wk.recA[r], wk.recA[r + P], wk.recA[r + 2 * P]);
@@ -870,9 +884,20 @@ RRT_DEV Staged stage_scene(const DScene& sc, unsigned char* smem) {
     uint32_t off = 0;
     if (sc.lds_mesh >= 0) {
         const DMesh M = sc.meshes[sc.lds_mesh];
-        const RRT_GLOBAL double* src = (const RRT_GLOBAL double*)M.nodes;   // 16 B = 2 doubles per node
-        double* dst = (double*)smem;
-        for (int32_t i = threadIdx.x; i < 2 * sc.lds_nodes; i += blockDim.x) dst[i] = src[i];
+        // one 16-byte node per thread and trip, four trips' loads in flight before the first store
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const RRT_GLOBAL u32x4* src = (const RRT_GLOBAL u32x4*)M.nodes;
+        RRT_LDS u32x4* dst = (RRT_LDS u32x4*)smem;
+        const int32_t n = sc.lds_nodes, step = (int32_t)blockDim.x;
+        for (int32_t i = threadIdx.x; i < n; i += 4 * step) {
+            const int32_t i1 = i + step, i2 = i + 2 * step, i3 = i + 3 * step;
+            const u32x4 v0 = src[i];
+            const u32x4 v1 = src[i1 < n ? i1 : i], v2 = src[i2 < n ? i2 : i], v3 = src[i3 < n ? i3 : i];
+            dst[i] = v0;
+            if (i1 < n) dst[i1] = v1;
+            if (i2 < n) dst[i2] = v2;
+            if (i3 < n) dst[i3] = v3;
+        }
         st.nodes = (const DNodeI*)smem;
         off = (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI);
     }
