@@ -119,10 +119,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    # Rehearsal of the N-rank path on a box with fewer GPUs (never used by the driver):
+    # RRT_BENCH_DEVICE pins every rank to one device, RRT_BENCH_BACKEND=gloo stages the gather through the host.
+    backend = os.environ.get("RRT_BENCH_BACKEND", "nccl")
+    if "RRT_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["RRT_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from rustraytracer_amd import host as Hst, scenes
     global W, H, SPP

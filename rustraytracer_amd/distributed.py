@@ -21,25 +21,39 @@ def alloc_tile_buffers(width, height, world, device):
     return local, gathered
 
 
+def _host_staged():
+    """gloo moves host memory: device tensors go through a host copy (rehearsals of the N-rank path
+    on one GPU, RRT_BENCH_BACKEND=gloo; the production backend is "nccl" = RCCL, device to device)."""
+    return dist.get_backend() == "gloo"
+
+
 def gather_tiles(local, gathered):
     """The frame's only collective.  Every rank ends with every rank's tiles."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         # output viewed as the concatenation along dim 0: the one layout both RCCL and gloo accept
-        dist.all_gather_into_tensor(gathered.view((-1,) + tuple(local.shape[1:])), local)
+        flat = gathered.view((-1,) + tuple(local.shape[1:]))
+        if local.is_cuda and _host_staged():
+            h_out = torch.empty(flat.shape, dtype=flat.dtype)
+            dist.all_gather_into_tensor(h_out, local.cpu())
+            flat.copy_(h_out)
+        else:
+            dist.all_gather_into_tensor(flat, local)
     else:
         gathered[0].copy_(local)
     return gathered
 
 
 def max_over_ranks(seconds, device):
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    multi = dist.is_initialized() and dist.get_world_size() > 1
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if multi and _host_staged() else device)
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def sum_over_ranks(values, device):
-    t = torch.tensor(list(values), dtype=torch.int64, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    multi = dist.is_initialized() and dist.get_world_size() > 1
+    t = torch.tensor(list(values), dtype=torch.int64, device="cpu" if multi and _host_staged() else device)
+    if multi:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(x) for x in t.tolist()]
