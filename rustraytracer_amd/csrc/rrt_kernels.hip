@@ -782,6 +782,37 @@ RRT_DEV void primary_ray(const DFrame& fr, uint32_t x, uint32_t y, uint32_t samp
     *d = normalize(lp - eye);
 }
 
+// Which pixel of its 32x8 tile thread t of a trace block takes.  Storage (accum, the compact tile
+// buffer) stays row-major inside the tile; only the thread -> pixel assignment is swizzled, so that a
+// wave covers a compact footprint: its 64 rays then mostly enter the same leaves.
+//   RRT_WAVE_SHAPE 0: 32x2 strip (thread order = storage order)   1: 8x8 block   2: 16x4 block
+#ifndef RRT_WAVE_SHAPE
+#define RRT_WAVE_SHAPE 1
+#endif
+__host__ __device__ inline uint32_t tile_swz(uint32_t t) {        // thread order -> storage order
+#if RRT_WAVE_SHAPE == 1
+    return ((t >> 3) & 7u) * 32u + (t >> 6) * 8u + (t & 7u);
+#elif RRT_WAVE_SHAPE == 2
+    const uint32_t w = t >> 6;
+    return ((w >> 1) * 4u + ((t >> 4) & 3u)) * 32u + (w & 1u) * 16u + (t & 15u);
+#else
+    return t;
+#endif
+}
+__host__ __device__ inline uint32_t tile_unswz(uint32_t in) {     // storage order -> thread order
+#if RRT_WAVE_SHAPE == 1
+    const uint32_t row = in >> 5, col = in & 31u;
+    return (col >> 3) * 64u + row * 8u + (col & 7u);
+#elif RRT_WAVE_SHAPE == 2
+    const uint32_t row = in >> 5, col = in & 31u;
+    return ((row >> 2) * 2u + (col >> 4)) * 64u + (row & 3u) * 16u + (col & 15u);
+#else
+    return in;
+#endif
+}
+// path-order local pixel index (what samp/records/queues are indexed by) -> storage-order index
+RRT_DEV uint32_t path_to_lp(uint32_t pp) { return (pp & ~255u) | tile_swz(pp & 255u); }
+
 RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y) {
     const uint32_t slot = lp >> 8, in = lp & 255u;
     const uint32_t tile = slot * fr.tile_world + fr.tile_rank;
@@ -934,7 +965,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         const uint32_t path = chunk * 256u + threadIdx.x;
         const uint32_t s_local = path / fr.npx_local, lp = path - s_local * fr.npx_local;
         uint32_t x = 0, y = 0;
-        const bool active = local_pixel(fr, lp, &x, &y);
+        const bool active = local_pixel(fr, path_to_lp(lp), &x, &y);
         const uint32_t sample = fr.s0 + s_local;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         if (active) primary_ray(fr, x, y, sample, &o, &d);
@@ -982,7 +1013,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
             // the RNG stream of the diffuse lobe is keyed by the global pixel and sample of the path
             const uint32_t s_local = path / fr.npx_local;
             uint32_t x = 0, y = 0;
-            local_pixel(fr, path - s_local * fr.npx_local, &x, &y);
+            local_pixel(fr, path_to_lp(path - s_local * fr.npx_local), &x, &y);
             pixel = y * fr.width + x;
             sample = fr.s0 + s_local;
         }
@@ -996,10 +1027,11 @@ __global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr) {
     if (lp >= fr.npx_local) return;
     const uint64_t P = wk.cap;
     const uint32_t N = fr.npx_local;
+    const uint32_t pp = (lp & ~255u) | tile_unswz(lp & 255u);   // where the trace kernels put this pixel's samples
     V3 acc = mk(0., 0., 0.);
     if (fr.s0 != 0u) acc = mk(wk.accum[lp], wk.accum[lp + N], wk.accum[lp + 2 * (size_t)N]);
     for (uint32_t s = 0; s < fr.ns; ++s) {
-        const size_t p = (size_t)s * N + lp;
+        const size_t p = (size_t)s * N + pp;
         const V3 c = mk(wk.samp[p], wk.samp[p + P], wk.samp[p + 2 * P]);
         acc = (fr.s0 + s == 0u) ? c : acc + c;
     }
