@@ -336,6 +336,7 @@ int commit(rrt_scene* s) {
     d.cull_mode = s->cull_mode;
     // the first mesh whose descent array fits is staged in LDS by the trace kernels
     d.lds_ents = (!s->ents.empty() && s->ents.size() <= (size_t)rrt::kMaxLdsEnts) ? 1 : 0;
+    d.lds_mats = s->mats.size() <= (size_t)rrt::kMaxLdsMats ? (int32_t)s->mats.size() : 0;
     d.lds_mesh = -1;
     d.lds_nodes = 0;
     for (size_t i = 0; i < s->meshes.size(); ++i)

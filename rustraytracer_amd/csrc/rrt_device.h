@@ -118,7 +118,8 @@ struct DScene {
     const DMaterial* mats;
     const DGroup* groups;
     int32_t n_groups;
-    int32_t pad1;
+    int32_t lds_mats;        // materials the trace kernels keep in LDS: all of them (<= kMaxLdsMats), or 0
+
     int32_t n_ents;
     int32_t has_light;
     double light_dir[3];
@@ -137,6 +138,7 @@ struct DScene {
 constexpr int32_t kGroup = 4;            // a leaf's run in the stream starts at a multiple of kGroup and is padded to one
 constexpr int32_t kStreamPad = 4;        // readable entries past the end of DMesh::tris / DMesh::grp
 constexpr int32_t kMaxLdsEnts = 64;      // 128 B of LDS per entity
+constexpr int32_t kMaxLdsMats = 64;      // 72 B of LDS per material
 constexpr int32_t kMaxLdsNodes = 3072;   // 48 KB of LDS per 256-thread block at most
 
 // Ray queue, SoA.  cap entries each.

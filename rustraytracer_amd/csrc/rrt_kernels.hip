@@ -33,6 +33,9 @@ namespace {
 #ifndef RRT_PROBE
 #define RRT_PROBE 0
 #endif
+#ifndef RRT_XCD_ORDER
+#define RRT_XCD_ORDER 1
+#endif
 #if RRT_PROBE
 __device__ unsigned long long g_phase[32];
 #define CNT(i)                                                                          \
@@ -213,6 +216,7 @@ RRT_DEV bool tri_collide(const TriData& T, V3 o, V3 d, double* tout) {
 
 struct Hit {
     bool hit;
+    bool sphere;     // the winner is a sphere (Refraction tracks the sphere a ray is inside)
     int32_t tri;
     int32_t mat;
     double t;
@@ -508,7 +512,22 @@ static_assert(sizeof(DSphere) <= 4 * (kEntRec - 2) && sizeof(DMesh) <= 4 * (kEnt
 struct Staged {
     const DNodeI* nodes;             // descent array of scene.lds_mesh, or nullptr
     const RRT_LDS uint32_t* ents;    // entity records, or nullptr (then everything is read from global memory)
+    const RRT_LDS uint32_t* mats;    // the scene's materials (sizeof(DMaterial) each), or nullptr
+    const RRT_LDS double* by255;     // i / 255.0 for i = 0..255 (cubemap.rs:70-74), or nullptr
 };
+constexpr Staged kNoLds{nullptr, nullptr, nullptr, nullptr};
+
+// Per-lane read of a field of an LDS-staged struct (the record index differs per lane).
+template <class T>
+RRT_DEV T lds_field(const RRT_LDS uint32_t* rec, size_t byte_off) {
+    static_assert(sizeof(T) % 4 == 0, "dword-sized fields only");
+    uint32_t w[sizeof(T) / 4];
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(T) / 4; ++i) w[i] = rec[byte_off / 4 + i];
+    T t;
+    __builtin_memcpy(&t, w, sizeof(T));
+    return t;
+}
 
 template <class T>
 RRT_DEV T lds_uniform(const RRT_LDS uint32_t* p) {
@@ -617,15 +636,36 @@ RRT_DEV void closest_hit(const DScene& sc, Staged lds, V3 o, V3 d, int32_t mediu
 
 // Rebuilds the ColliderResult of the winning entity: position (sphere.rs:39 / triangle.rs:53),
 // normal (sphere.rs:45 / the triangle's stored normal, triangle.rs:54), material.
-RRT_DEV void finish_hit(const DScene& sc, V3 o, V3 d, const Closest& c, Hit* h) {
+// With the entity table in LDS the winner's record comes from there (per-lane index): from global
+// memory it is two dependent loads (entity -> its sphere / mesh struct) in front of the normal's.
+RRT_DEV void finish_hit(const DScene& sc, Staged lds, V3 o, V3 d, const Closest& c, Hit* h) {
     h->hit = c.ent >= 0;
-    h->tri = -1; h->mat = -1; h->t = 0.0;
+    h->tri = -1; h->mat = -1; h->t = 0.0; h->sphere = false;
     h->pos = mk(0., 0., 0.); h->normal = mk(0., 0., 0.);
     if (!h->hit) return;
-    DEntity ent = sc.ents[c.ent];
-    ent.kind &= ~kEntityMember;
     h->t = c.t;
     h->pos = o + d * c.t;
+    if (lds.ents) {
+        const RRT_LDS uint32_t* rec = lds.ents + c.ent * kEntRec;
+        h->sphere = ((int32_t)rec[0] & ~kEntityMember) == 0;
+        if (h->sphere) {
+            const V3 ctr = mk(lds_field<double>(rec, 8 + offsetof(DSphere, c)), lds_field<double>(rec, 8 + offsetof(DSphere, c) + 8),
+                              lds_field<double>(rec, 8 + offsetof(DSphere, c) + 16));
+            h->normal = normalize(h->pos - ctr);
+            h->mat = lds_field<int32_t>(rec, 8 + offsetof(DSphere, material));
+        } else {
+            const int32_t* refs = lds_field<const int32_t*>(rec, 8 + offsetof(DMesh, leaf_refs));
+            const double* nrm = lds_field<const double*>(rec, 8 + offsetof(DMesh, normals));
+            const int32_t id = as_global(refs)[c.entry];
+            h->tri = id;
+            h->normal = ld3g(as_global(nrm) + 3 * (size_t)id);
+            h->mat = lds_field<int32_t>(rec, 8 + offsetof(DMesh, material));
+        }
+        return;
+    }
+    DEntity ent = sc.ents[c.ent];
+    ent.kind &= ~kEntityMember;
+    h->sphere = ent.kind == 0;
     if (ent.kind == 0) {
         const DSphere* S = sc.spheres + ent.index;
         h->normal = normalize(h->pos - ld3(S->c));
@@ -637,6 +677,11 @@ RRT_DEV void finish_hit(const DScene& sc, V3 o, V3 d, const Closest& c, Hit* h) 
         h->normal = ld3g(as_global(M->normals) + 3 * (size_t)id);
         h->mat = M->material;
     }
+}
+
+RRT_DEV DMaterial load_material(const DScene& sc, Staged lds, int32_t mat) {
+    if (lds.mats) return lds_field<DMaterial>(lds.mats + mat * (int32_t)(sizeof(DMaterial) / 4), 0);
+    return sc.mats[mat];
 }
 
 // texel / 255.0 (cubemap.rs:70-74) for the 256 possible texel values, divided at compile time
@@ -651,7 +696,7 @@ struct By255 {
 __device__ const By255 kBy255{};
 
 // cubemap() + CubemapBehavior::compute (cubemap.rs:84-164, 56-77)
-RRT_DEV V3 sky_color(const DScene& sc, V3 dir) {
+RRT_DEV V3 sky_color(const DScene& sc, Staged lds, V3 dir) {
     const double x = dir.x, y = dir.y, z = dir.z;
     const double ax = fabs(x), ay = fabs(y), az = fabs(z);
     const bool xp = x > 0.0, yp = y > 0.0, zp = z > 0.0;
@@ -671,6 +716,7 @@ RRT_DEV V3 sky_color(const DScene& sc, V3 dir) {
     if (py >= hgt) py = hgt - 1;
     const uint8_t* p = sc.sky[idx] + ((size_t)py * w + px) * 3;
 #ifndef RRT_NO_LUT
+    if (lds.by255) return mk(lds.by255[p[0]], lds.by255[p[1]], lds.by255[p[2]]);
     return mk(kBy255.v[p[0]], kBy255.v[p[1]], kBy255.v[p[2]]);
 #else
     return mk((double)p[0] / 255.0, (double)p[1] / 255.0, (double)p[2] / 255.0);
@@ -837,7 +883,7 @@ RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DF
         CNT(0);
         closest_hit<CULL, GROUPS>(sc, lds, o, d, medium, &c, wk.stats);
         Hit h;
-        finish_hit(sc, o, d, c, &h);
+        finish_hit(sc, lds, o, d, c, &h);
         const int32_t ent = c.ent;
         if (PRIMARY && aov) {
             if (d_ids) { d_ids[2 * (size_t)pixel] = ent; d_ids[2 * (size_t)pixel + 1] = h.tri; }
@@ -846,7 +892,7 @@ RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DF
         V3 col;
         uint32_t fold_from = bounce;        // records [0, fold_from) still enclose col
         if (h.hit) {
-            const DMaterial m = sc.mats[h.mat];
+            const DMaterial m = load_material(sc, lds, h.mat);
             V3 A, Pm;
             CNT(9);
             shade_direct(sc, m, d, h.normal, &A, &Pm);
@@ -856,14 +902,13 @@ RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DF
                 wk.recA[r] = A.x; wk.recA[r + P] = A.y; wk.recA[r + 2 * P] = A.z;
                 wk.recP[r] = Pm.x; wk.recP[r + P] = Pm.y; wk.recP[r + 2 * P] = Pm.z;
                 wk.recR[(size_t)bounce * P + path] = m.mixR;
-                continuation(fr, m, h.pos, h.normal, d, (sc.ents[ent].kind & ~kEntityMember) == 0, ent, bounce, pixel, sample, &ro, &rd,
-                             &medium);
+                continuation(fr, m, h.pos, h.normal, d, h.sphere, ent, bounce, pixel, sample, &ro, &rd, &medium);
             } else {
                 col = A + Pm;   // Reflection returned None (reflection.rs:26-28) or was pruned
             }
         } else if (PRIMARY) {
             CNT(8);
-            col = sky_color(sc, d);
+            col = sky_color(sc, lds, d);
         } else {
             // A bounce ray that leaves the scene ends its path (most do).  Its innermost enclosing
             // record is requested BEFORE the sky texel: both are HBM misses on incoherent addresses,
@@ -874,7 +919,7 @@ RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DF
             const double mr = wk.recR[(size_t)k * P + path];
             const V3 A = mk(wk.recA[r], wk.recA[r + P], wk.recA[r + 2 * P]);
             const V3 Pm = mk(wk.recP[r], wk.recP[r + P], wk.recP[r + 2 * P]);
-            col = sky_color(sc, d);
+            col = sky_color(sc, lds, d);
             col = (A + col * mr) + Pm;
             fold_from = k;
         }
@@ -905,13 +950,14 @@ RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DF
 // counter sits right behind them.
 __host__ __device__ inline uint32_t lds_layout_bytes(const DScene& sc) {
     return (sc.lds_mesh >= 0 ? (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI) : 0u) +
-           (sc.lds_ents ? (uint32_t)sc.n_ents * (uint32_t)kEntRec * 4u : 0u);
+           (sc.lds_ents ? (uint32_t)sc.n_ents * (uint32_t)kEntRec * 4u : 0u) +
+           (uint32_t)sc.lds_mats * (uint32_t)sizeof(DMaterial) + 256u * 8u;
 }
 
 // Fills the block's LDS (all threads; ends with a barrier): the descent array of scene.lds_mesh and,
 // after it, the entity records.  Either part may be absent (see DScene::lds_mesh / lds_ents).
 RRT_DEV Staged stage_scene(const DScene& sc, unsigned char* smem) {
-    Staged st{nullptr, nullptr};
+    Staged st = kNoLds;
     uint32_t off = 0;
     if (sc.lds_mesh >= 0) {
         const DMesh M = sc.meshes[sc.lds_mesh];
@@ -949,6 +995,22 @@ RRT_DEV Staged stage_scene(const DScene& sc, unsigned char* smem) {
             tab[i] = v;
         }
         st.ents = tab;
+        off += (uint32_t)sc.n_ents * (uint32_t)kEntRec * 4u;
+    }
+    if (sc.lds_mats > 0) {
+        RRT_LDS uint32_t* tab = (RRT_LDS uint32_t*)(smem + off);
+        const uint32_t* src = (const uint32_t*)sc.mats;
+        const int32_t n = sc.lds_mats * (int32_t)(sizeof(DMaterial) / 4);
+        for (int32_t i = threadIdx.x; i < n; i += blockDim.x) tab[i] = src[i];
+        st.mats = tab;
+        off += (uint32_t)n * 4u;
+    }
+    {
+        // texel / 255.0 for the 256 texel values: one IEEE division per thread (the reference's own
+        // expression, cubemap.rs:70-74), read back per lane at ~LDS latency instead of a global load
+        RRT_LDS double* tab = (RRT_LDS double*)(smem + off);
+        for (int32_t i = threadIdx.x; i < 256; i += blockDim.x) tab[i] = (double)i / 255.0;
+        st.by255 = tab;
     }
     __syncthreads();
     return st;
@@ -961,7 +1023,25 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
     extern __shared__ __align__(16) unsigned char smem[];
     const Staged lds = stage_scene(sc, smem);
     const uint32_t n_chunks = (uint32_t)(((uint64_t)fr.ns * fr.npx_local) >> 8);   // 256 paths per chunk, exact
+#if RRT_XCD_ORDER
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes the tiles
+    // t = x (mod 8), and its blocks walk them tile-major (all samples of a tile back to back, on
+    // neighbouring blocks of the same XCD), so what one sample of a tile pulls in -- its leaves and
+    // triangles, the sky texel lines behind it -- is in that L2 for the other samples.
+    const uint32_t n_tiles = fr.npx_local >> 8;
+    const bool by_xcd = (gridDim.x & 7u) == 0u && n_tiles >= 8u;
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t limit = by_xcd ? ((n_tiles + 7u - xcd) >> 3) * fr.ns : n_chunks;
+    const uint32_t step = by_xcd ? gridDim.x >> 3 : gridDim.x;
+    for (uint32_t m = by_xcd ? blockIdx.x >> 3 : blockIdx.x; m < limit; m += step) {
+        uint32_t chunk = m;
+        if (by_xcd) {
+            const uint32_t k = m / fr.ns, s = m - k * fr.ns;
+            chunk = s * n_tiles + xcd + 8u * k;
+        }
+#else
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+#endif
         const uint32_t path = chunk * 256u + threadIdx.x;
         const uint32_t s_local = path / fr.npx_local, lp = path - s_local * fr.npx_local;
         uint32_t x = 0, y = 0;
@@ -1079,11 +1159,11 @@ __global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* ray
     if (i >= n) return;
     const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
     Closest c;
-    if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, Staged{nullptr, nullptr}, o, d, -1, &c, stats);
-    else if (sc.cull_mode == 1) closest_hit<1, GROUPS>(sc, Staged{nullptr, nullptr}, o, d, -1, &c, stats);
-    else closest_hit<2, GROUPS>(sc, Staged{nullptr, nullptr}, o, d, -1, &c, stats);
+    if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, kNoLds, o, d, -1, &c, stats);
+    else if (sc.cull_mode == 1) closest_hit<1, GROUPS>(sc, kNoLds, o, d, -1, &c, stats);
+    else closest_hit<2, GROUPS>(sc, kNoLds, o, d, -1, &c, stats);
     Hit h;
-    finish_hit(sc, o, d, c, &h);
+    finish_hit(sc, kNoLds, o, d, c, &h);
     const int32_t e = c.ent;
     if (ent) ent[i] = e;
     if (tri) tri[i] = h.tri;
@@ -1107,11 +1187,11 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
     V3 col;
     for (;;) {
         Closest c;
-        if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, Staged{nullptr, nullptr}, o, d, medium, &c, stats);
-        else closest_hit<2, GROUPS>(sc, Staged{nullptr, nullptr}, o, d, medium, &c, stats);
+        if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, kNoLds, o, d, medium, &c, stats);
+        else closest_hit<2, GROUPS>(sc, kNoLds, o, d, medium, &c, stats);
         Hit h;
-        finish_hit(sc, o, d, c, &h);
-        if (!h.hit) { col = sky_color(sc, d); break; }
+        finish_hit(sc, kNoLds, o, d, c, &h);
+        if (!h.hit) { col = sky_color(sc, kNoLds, d); break; }
         const DMaterial m = sc.mats[h.mat];
         V3 A, Pm;
         shade_direct(sc, m, d, h.normal, &A, &Pm);
@@ -1119,8 +1199,7 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
         if (!cont) { col = A + Pm; break; }
         sA[bounce] = A; sP[bounce] = Pm; sR[bounce] = m.mixR;
         V3 ro, rd;
-        continuation(fr, m, h.pos, h.normal, d, (sc.ents[c.ent].kind & ~kEntityMember) == 0, c.ent, bounce, (uint32_t)i, 0u, &ro, &rd,
-                     &medium);
+        continuation(fr, m, h.pos, h.normal, d, h.sphere, c.ent, bounce, (uint32_t)i, 0u, &ro, &rd, &medium);
         o = ro; d = rd; ++bounce;
     }
     for (uint32_t k = bounce; k-- > 0;) col = (sA[k] + col * sR[k]) + sP[k];
