@@ -33,6 +33,9 @@ namespace {
 #ifndef RRT_PROBE
 #define RRT_PROBE 0
 #endif
+#ifndef RRT_ABL
+#define RRT_ABL 0
+#endif
 #ifndef RRT_XCD_ORDER
 #define RRT_XCD_ORDER 1
 #endif
@@ -510,12 +513,30 @@ constexpr int32_t kEntRec = 32;
 static_assert(sizeof(DSphere) <= 4 * (kEntRec - 2) && sizeof(DMesh) <= 4 * (kEntRec - 2) && sizeof(DGroup) <= 4 * (kEntRec - 2),
               "entity record too small");
 struct Staged {
+    static constexpr bool kStaged = true;
     const DNodeI* nodes;             // descent array of scene.lds_mesh, or nullptr
     const RRT_LDS uint32_t* ents;    // entity records, or nullptr (then everything is read from global memory)
     const RRT_LDS uint32_t* mats;    // the scene's materials (sizeof(DMaterial) each), or nullptr
-    const RRT_LDS double* by255;     // i / 255.0 for i = 0..255 (cubemap.rs:70-74), or nullptr
+    const RRT_LDS double* by255;     // i / 255.0 for i = 0..255 (cubemap.rs:70-74)
+    const RRT_LDS double* consts;    // light, ambient, camera, sky faces (kC* below)
 };
-constexpr Staged kNoLds{nullptr, nullptr, nullptr, nullptr};
+// What the one-thread-per-ray test kernels pass: nothing is staged, every branch on it folds away.
+struct NoLds {
+    static constexpr bool kStaged = false;
+    static constexpr const DNodeI* nodes = nullptr;
+    static constexpr const RRT_LDS uint32_t* ents = nullptr;
+    static constexpr const RRT_LDS uint32_t* mats = nullptr;
+    static constexpr const RRT_LDS double* by255 = nullptr;
+    static constexpr const RRT_LDS double* consts = nullptr;
+};
+constexpr NoLds kNoLds{};
+// The block of per-frame constants a trace block keeps in LDS.  As kernel arguments they sit in
+// ~60 SGPRs for the whole kernel (the SGPR file holds ~100; the rest is spilled to VGPR lanes and
+// read back with v_readlane, a VALU slot each), and the six sky faces are picked per lane with
+// select chains.  From LDS they arrive where they are used, as VGPR operands: indices in doubles.
+constexpr int32_t kCLightDir = 0, kCLightColor = 3, kCIntensity = 6, kCAmbient = 7, kCEye = 8, kCLensZ = 11,
+                  kCLensW = 12, kCLensH = 13, kCFaces = 14 /* 6 x {ptr, w, h}: 2 doubles each */, kCDoubles = 26;
+RRT_DEV V3 ld3l(const RRT_LDS double* p) { return V3{p[0], p[1], p[2]}; }
 
 // Per-lane read of a field of an LDS-staged struct (the record index differs per lane).
 template <class T>
@@ -547,6 +568,8 @@ RRT_DEV T lds_uniform(const RRT_LDS uint32_t* p) {
 template <int CULL>
 RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LDS uint32_t* rec, int32_t e, DEntity ent,
                             V3 o, V3 d, int32_t medium, Closest* best, unsigned long long* stats) {
+    if ((RRT_ABL & 4) && ent.kind == 0) return;
+    if ((RRT_ABL & 2) && ent.kind != 0) return;
     if (ent.kind == 0) {
         double t;
         const DSphere S = rec ? lds_uniform<DSphere>(rec + 2) : sc.spheres[ent.index];
@@ -612,8 +635,8 @@ RRT_DEV void group_collide(const DScene& sc, const DGroup& G, const DNodeI* lnod
 
 // The entity loop of RayTracer::cast (tracer.rs:178-190).  GROUPS: the scene holds Scene<T>
 // entities (kind 2); their members carry kEntityMember and are not in world.entities.
-template <int CULL, bool GROUPS>
-RRT_DEV void closest_hit(const DScene& sc, Staged lds, V3 o, V3 d, int32_t medium, Closest* best,
+template <int CULL, bool GROUPS, class LDS>
+RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, Closest* best,
                          unsigned long long* stats) {
     const DNodeI* lnodes = lds.nodes;
     best->dist = kF64Max; best->t = 0.0; best->ent = -1; best->entry = -1;
@@ -638,7 +661,8 @@ RRT_DEV void closest_hit(const DScene& sc, Staged lds, V3 o, V3 d, int32_t mediu
 // normal (sphere.rs:45 / the triangle's stored normal, triangle.rs:54), material.
 // With the entity table in LDS the winner's record comes from there (per-lane index): from global
 // memory it is two dependent loads (entity -> its sphere / mesh struct) in front of the normal's.
-RRT_DEV void finish_hit(const DScene& sc, Staged lds, V3 o, V3 d, const Closest& c, Hit* h) {
+template <class LDS>
+RRT_DEV void finish_hit(const DScene& sc, LDS lds, V3 o, V3 d, const Closest& c, Hit* h) {
     h->hit = c.ent >= 0;
     h->tri = -1; h->mat = -1; h->t = 0.0; h->sphere = false;
     h->pos = mk(0., 0., 0.); h->normal = mk(0., 0., 0.);
@@ -679,7 +703,8 @@ RRT_DEV void finish_hit(const DScene& sc, Staged lds, V3 o, V3 d, const Closest&
     }
 }
 
-RRT_DEV DMaterial load_material(const DScene& sc, Staged lds, int32_t mat) {
+template <class LDS>
+RRT_DEV DMaterial load_material(const DScene& sc, LDS lds, int32_t mat) {
     if (lds.mats) return lds_field<DMaterial>(lds.mats + mat * (int32_t)(sizeof(DMaterial) / 4), 0);
     return sc.mats[mat];
 }
@@ -696,7 +721,9 @@ struct By255 {
 __device__ const By255 kBy255{};
 
 // cubemap() + CubemapBehavior::compute (cubemap.rs:84-164, 56-77)
-RRT_DEV V3 sky_color(const DScene& sc, Staged lds, V3 dir) {
+template <class LDS>
+RRT_DEV V3 sky_color(const DScene& sc, LDS lds, V3 dir) {
+    if (RRT_ABL & 1) return dir;
     const double x = dir.x, y = dir.y, z = dir.z;
     const double ax = fabs(x), ay = fabs(y), az = fabs(z);
     const bool xp = x > 0.0, yp = y > 0.0, zp = z > 0.0;
@@ -710,13 +737,22 @@ RRT_DEV V3 sky_color(const DScene& sc, Staged lds, V3 dir) {
     if (!zp && az >= ax && az >= ay) { max_axis = az; uc = -x; vc = y; idx = 5; }
     const double u = 0.5 * (uc / max_axis + 1.0);
     const double v = 0.5 * (vc / max_axis + 1.0);
-    const uint32_t w = sc.sky_w[idx], hgt = sc.sky_h[idx];
+    uint32_t w, hgt;
+    const uint8_t* face;
+    if constexpr (LDS::kStaged) {
+        const RRT_LDS uint32_t* f = (const RRT_LDS uint32_t*)(lds.consts + kCFaces) + 4u * idx;
+        face = lds_field<const uint8_t*>(f, 0);
+        w = f[2]; hgt = f[3];
+    } else {
+        w = sc.sky_w[idx]; hgt = sc.sky_h[idx];
+        face = sc.sky[idx];
+    }
     uint32_t px = sat_u32(u * (double)w), py = sat_u32(v * (double)hgt);
     if (px >= w) px = w - 1;
     if (py >= hgt) py = hgt - 1;
-    const uint8_t* p = sc.sky[idx] + ((size_t)py * w + px) * 3;
+    const uint8_t* p = face + ((size_t)py * w + px) * 3;
 #ifndef RRT_NO_LUT
-    if (lds.by255) return mk(lds.by255[p[0]], lds.by255[p[1]], lds.by255[p[2]]);
+    if constexpr (LDS::kStaged) return mk(lds.by255[p[0]], lds.by255[p[1]], lds.by255[p[2]]);
     return mk(kBy255.v[p[0]], kBy255.v[p[1]], kBy255.v[p[2]]);
 #else
     return mk((double)p[0] / 255.0, (double)p[1] / 255.0, (double)p[2] / 255.0);
@@ -725,19 +761,28 @@ RRT_DEV V3 sky_color(const DScene& sc, Staged lds, V3 dir) {
 
 // Direct terms of a hit (tracer.rs:194-202 with lambert.rs:22-45, phong.rs:25-47):
 //   A  = color*ambient + Lambert*mixL      Pm = Phong*mixP
-RRT_DEV void shade_direct(const DScene& sc, const DMaterial& m, V3 d, V3 normal, V3* A, V3* Pm) {
+template <class LDS>
+RRT_DEV void shade_direct(const DScene& sc, LDS lds, const DMaterial& m, V3 d, V3 normal, V3* A, V3* Pm) {
     const V3 color = ld3(m.color);
-    V3 fin = color * sc.ambient;
-    const V3 L = ld3(sc.light_dir);
+    double ambient, intensity;
+    V3 L, lcolor;
+    if constexpr (LDS::kStaged) {
+        ambient = lds.consts[kCAmbient]; intensity = lds.consts[kCIntensity];
+        L = ld3l(lds.consts + kCLightDir); lcolor = ld3l(lds.consts + kCLightColor);
+    } else {
+        ambient = sc.ambient; intensity = sc.light_intensity;
+        L = ld3(sc.light_dir); lcolor = ld3(sc.light_color);
+    }
+    V3 fin = color * ambient;
     const bool visible = sc.has_light && (dot(normal, L) < 0.);   // lighting.rs:43-45
     V3 lam = mk(0., 0., 0.), ph = mk(0., 0., 0.);
     if (visible) {
-        double power = sc.light_intensity * (m.albedo / 3.14159265358979323846) * -dot(normal, L);
+        double power = intensity * (m.albedo / 3.14159265358979323846) * -dot(normal, L);
         power = fmax(power, 0.);
         lam = lam + color * power;
         const V3 bis = normalize(neg(L) - d);
-        const double pw = sc.light_intensity * powi(fmax(dot(bis, normal), 0.), m.alpha);
-        ph = ph + ld3(sc.light_color) * pw;
+        const double pw = intensity * powi(fmax(dot(bis, normal), 0.), m.alpha);
+        ph = ph + lcolor * pw;
     }
     *A = fin + lam * m.mixL;
     *Pm = ph * m.mixP;
@@ -809,18 +854,27 @@ RRT_DEV uint32_t queue_slot(uint32_t* counter, bool want) {
 }
 
 // tracer.rs:84-110, 126-131 with the sub-pixel jitter extension.
-RRT_DEV void primary_ray(const DFrame& fr, uint32_t x, uint32_t y, uint32_t sample, V3* o, V3* d) {
+template <class LDS>
+RRT_DEV void primary_ray(const DFrame& fr, LDS lds, uint32_t x, uint32_t y, uint32_t sample, V3* o, V3* d) {
     double jx = 0.0, jy = 0.0;
-    if (sample != 0u) {
+    if (sample != 0u && !(RRT_ABL & 8)) {
         uint32_t r[4];
         philox4x32_10(y * fr.width + x, sample, 0u, 0u, fr.seed_lo, fr.seed_hi, r);
         jx = (double)r[0] * (1.0 / 4294967296.0);
         jy = (double)r[1] * (1.0 / 4294967296.0);
     }
-    const V3 eye = mk(fr.cam.eye[0], fr.cam.eye[1], fr.cam.eye[2]);
-    const V3 lens_pos = eye + mk(0.0, 0.0, fr.cam.lens_z);
-    const V3 ll = lens_pos - mk(fr.cam.lens_w / 2.0, fr.cam.lens_h / 2.0, 0.0);
-    const V3 lh = mk(fr.cam.lens_w, 0.0, 0.0), lv = mk(0.0, fr.cam.lens_h, 0.0);
+    V3 eye;
+    double lens_z, lens_w, lens_h;
+    if constexpr (LDS::kStaged) {
+        eye = ld3l(lds.consts + kCEye);
+        lens_z = lds.consts[kCLensZ]; lens_w = lds.consts[kCLensW]; lens_h = lds.consts[kCLensH];
+    } else {
+        eye = mk(fr.cam.eye[0], fr.cam.eye[1], fr.cam.eye[2]);
+        lens_z = fr.cam.lens_z; lens_w = fr.cam.lens_w; lens_h = fr.cam.lens_h;
+    }
+    const V3 lens_pos = eye + mk(0.0, 0.0, lens_z);
+    const V3 ll = lens_pos - mk(lens_w / 2.0, lens_h / 2.0, 0.0);
+    const V3 lh = mk(lens_w, 0.0, 0.0), lv = mk(0.0, lens_h, 0.0);
     const double fx = ((double)x + jx) / (double)fr.width;
     const double fy = ((double)y + jy) / (double)fr.height;
     const V3 lp = (ll + lh * fx) + lv * fy;
@@ -870,8 +924,8 @@ RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y
 }
 
 // One cast() (tracer.rs:177-211) of path `path` at depth `bounce`.
-template <bool PRIMARY, int CULL, bool GROUPS>
-RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DFrame& fr, bool active,
+template <bool PRIMARY, int CULL, bool GROUPS, class LDS>
+RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFrame& fr, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
                          uint32_t pixel, uint32_t sample) {
     const uint64_t P = wk.cap;
@@ -895,7 +949,7 @@ RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DF
             const DMaterial m = load_material(sc, lds, h.mat);
             V3 A, Pm;
             CNT(9);
-            shade_direct(sc, m, d, h.normal, &A, &Pm);
+            shade_direct(sc, lds, m, d, h.normal, &A, &Pm);
             cont = !(bounce > fr.max_bounce) && !(fr.prune && m.mixR == 0.0);
             if (cont) {
                 const size_t r = (size_t)bounce * 3 * P + path;
@@ -933,7 +987,8 @@ RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DF
                 const V3 Pm = mk(wk.recP[r], wk.recP[r + P], wk.recP[r + 2 * P]);
                 col = (A + col * mr) + Pm;
             }
-            wk.samp[path] = col.x; wk.samp[path + P] = col.y; wk.samp[path + 2 * P] = col.z;
+            if (!(RRT_ABL & 16) || col.x == 12345.678) {
+            wk.samp[path] = col.x; wk.samp[path + P] = col.y; wk.samp[path + 2 * P] = col.z; }
         }
     }
     const uint32_t slot = queue_slot(&wk.q_count[bounce + 1], cont);
@@ -951,13 +1006,13 @@ RRT_DEV void process_ray(const DScene& sc, Staged lds, const DWork& wk, const DF
 __host__ __device__ inline uint32_t lds_layout_bytes(const DScene& sc) {
     return (sc.lds_mesh >= 0 ? (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI) : 0u) +
            (sc.lds_ents ? (uint32_t)sc.n_ents * (uint32_t)kEntRec * 4u : 0u) +
-           (uint32_t)sc.lds_mats * (uint32_t)sizeof(DMaterial) + 256u * 8u;
+           (uint32_t)sc.lds_mats * (uint32_t)sizeof(DMaterial) + 256u * 8u + (uint32_t)kCDoubles * 8u;
 }
 
 // Fills the block's LDS (all threads; ends with a barrier): the descent array of scene.lds_mesh and,
 // after it, the entity records.  Either part may be absent (see DScene::lds_mesh / lds_ents).
-RRT_DEV Staged stage_scene(const DScene& sc, unsigned char* smem) {
-    Staged st = kNoLds;
+RRT_DEV Staged stage_scene(const DScene& sc, const DFrame& fr, unsigned char* smem) {
+    Staged st{nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t off = 0;
     if (sc.lds_mesh >= 0) {
         const DMesh M = sc.meshes[sc.lds_mesh];
@@ -1011,6 +1066,28 @@ RRT_DEV Staged stage_scene(const DScene& sc, unsigned char* smem) {
         RRT_LDS double* tab = (RRT_LDS double*)(smem + off);
         for (int32_t i = threadIdx.x; i < 256; i += blockDim.x) tab[i] = (double)i / 255.0;
         st.by255 = tab;
+        off += 256u * 8u;
+    }
+    {
+        RRT_LDS double* c = (RRT_LDS double*)(smem + off);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                c[kCLightDir + a] = sc.light_dir[a];
+                c[kCLightColor + a] = sc.light_color[a];
+                c[kCEye + a] = fr.cam.eye[a];
+            }
+            c[kCIntensity] = sc.light_intensity; c[kCAmbient] = sc.ambient;
+            c[kCLensZ] = fr.cam.lens_z; c[kCLensW] = fr.cam.lens_w; c[kCLensH] = fr.cam.lens_h;
+            RRT_LDS uint32_t* f = (RRT_LDS uint32_t*)(c + kCFaces);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const uint64_t p = (uint64_t)sc.sky[i];
+                f[4 * i] = (uint32_t)p; f[4 * i + 1] = (uint32_t)(p >> 32);
+                f[4 * i + 2] = sc.sky_w[i]; f[4 * i + 3] = sc.sky_h[i];
+            }
+        }
+        st.consts = c;
     }
     __syncthreads();
     return st;
@@ -1021,7 +1098,7 @@ RRT_DEV Staged stage_scene(const DScene& sc, unsigned char* smem) {
 template <int CULL, bool GROUPS>
 __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const Staged lds = stage_scene(sc, smem);
+    const Staged lds = stage_scene(sc, fr, smem);
     const uint32_t n_chunks = (uint32_t)(((uint64_t)fr.ns * fr.npx_local) >> 8);   // 256 paths per chunk, exact
 #if RRT_XCD_ORDER
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes the tiles
@@ -1048,7 +1125,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         const bool active = local_pixel(fr, path_to_lp(lp), &x, &y);
         const uint32_t sample = fr.s0 + s_local;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-        if (active) primary_ray(fr, x, y, sample, &o, &d);
+        if (active) primary_ray(fr, lds, x, y, sample, &o, &d);
         process_ray<true, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample);
     }
 }
@@ -1071,7 +1148,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
     const uint32_t my_units = (n_units - blockIdx.x + gridDim.x - 1u) / gridDim.x;
     RRT_LDS uint32_t* next_unit = (RRT_LDS uint32_t*)(smem + lds_layout_bytes(sc));
     if (threadIdx.x == 0) *next_unit = 0u;
-    const Staged lds = stage_scene(sc, smem);   // ends with the barrier that also publishes *next_unit
+    const Staged lds = stage_scene(sc, fr, smem);   // ends with the barrier that also publishes *next_unit
     const uint64_t P = wk.cap;
     const DQueue& q = wk.q[bounce & 1];
     const uint32_t lane = threadIdx.x & 63u;
@@ -1194,7 +1271,7 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
         if (!h.hit) { col = sky_color(sc, kNoLds, d); break; }
         const DMaterial m = sc.mats[h.mat];
         V3 A, Pm;
-        shade_direct(sc, m, d, h.normal, &A, &Pm);
+        shade_direct(sc, kNoLds, m, d, h.normal, &A, &Pm);
         const bool cont = !(bounce > max_bounce) && !(prune && m.mixR == 0.0);
         if (!cont) { col = A + Pm; break; }
         sA[bounce] = A; sP[bounce] = Pm; sR[bounce] = m.mixR;
