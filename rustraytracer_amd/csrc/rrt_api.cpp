@@ -335,8 +335,9 @@ int commit(rrt_scene* s) {
     d.ambient = s->ambient;
     d.cull_mode = s->cull_mode;
     // the first mesh whose descent array fits is staged in LDS by the trace kernels
-    d.lds_ents = (!s->ents.empty() && s->ents.size() <= (size_t)rrt::kMaxLdsEnts) ? 1 : 0;
-    d.lds_mats = s->mats.size() <= (size_t)rrt::kMaxLdsMats ? (int32_t)s->mats.size() : 0;
+    // small scenes (the reference's are: 1-4 entities): entity table and materials live in LDS
+    d.lds_ents = (!s->ents.empty() && s->ents.size() <= (size_t)rrt::kMaxLdsEnts && s->mats.size() <= (size_t)rrt::kMaxLdsMats) ? 1 : 0;
+    d.lds_mats = d.lds_ents ? (int32_t)s->mats.size() : 0;
     d.lds_mesh = -1;
     d.lds_nodes = 0;
     for (size_t i = 0; i < s->meshes.size(); ++i)
@@ -397,8 +398,8 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
     uint64_t max_spp = s->work_budget / ((uint64_t)bpp * fr.npx_local);
     if (st->batch_spp) max_spp = st->batch_spp;
     if (max_spp == 0) return fail(RRT_E_NOMEM, "work budget too small for one sample per pixel (rrt_set_work_budget)");
-    // keep path ids in 32 bits
-    max_spp = std::min<uint64_t>(max_spp, 0xffffffffull / fr.npx_local);
+    // keep a path's byte offset in the f64 work arrays (8 * path id) in 32 bits: the kernels address them that way
+    max_spp = std::min<uint64_t>(max_spp, 0x1fffffffull / fr.npx_local);
     if (max_spp == 0) return fail(RRT_E_NOMEM, "frame too large");
     out->n_batches = (uint32_t)((st->spp + max_spp - 1) / max_spp);
     out->batch_spp = (st->spp + out->n_batches - 1) / out->n_batches;

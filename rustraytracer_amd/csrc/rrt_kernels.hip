@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "rrt_device.h"
 
@@ -512,17 +513,23 @@ struct Closest {
 constexpr int32_t kEntRec = 32;
 static_assert(sizeof(DSphere) <= 4 * (kEntRec - 2) && sizeof(DMesh) <= 4 * (kEntRec - 2) && sizeof(DGroup) <= 4 * (kEntRec - 2),
               "entity record too small");
-struct Staged {
+// SMALL (kernel template parameter, = DScene::lds_ents): the entity table and the materials are in
+// LDS too.  A compile-time choice, so that the kernels of small scenes carry no global-memory
+// fallback (its five base pointers alone would sit in ten SGPRs through the whole kernel).
+template <bool SMALL>
+struct StagedT {
     static constexpr bool kStaged = true;
+    static constexpr bool kSmall = SMALL;
     const DNodeI* nodes;             // descent array of scene.lds_mesh, or nullptr
-    const RRT_LDS uint32_t* ents;    // entity records, or nullptr (then everything is read from global memory)
-    const RRT_LDS uint32_t* mats;    // the scene's materials (sizeof(DMaterial) each), or nullptr
+    const RRT_LDS uint32_t* ents;    // SMALL: entity records
+    const RRT_LDS uint32_t* mats;    // SMALL: the scene's materials (sizeof(DMaterial) each)
     const RRT_LDS double* by255;     // i / 255.0 for i = 0..255 (cubemap.rs:70-74)
     const RRT_LDS double* consts;    // light, ambient, camera, sky faces (kC* below)
 };
 // What the one-thread-per-ray test kernels pass: nothing is staged, every branch on it folds away.
 struct NoLds {
     static constexpr bool kStaged = false;
+    static constexpr bool kSmall = false;
     static constexpr const DNodeI* nodes = nullptr;
     static constexpr const RRT_LDS uint32_t* ents = nullptr;
     static constexpr const RRT_LDS uint32_t* mats = nullptr;
@@ -565,14 +572,16 @@ RRT_DEV T lds_uniform(const RRT_LDS uint32_t* p) {
 // loop (tracer.rs:183-188) and a kd leaf over entities (kdtree.rs:204-211) apply: strict <, so the
 // first of equals stays.
 // `rec` != nullptr: entity e's LDS record (e is wave-uniform then); nullptr: read from global memory.
-template <int CULL>
+template <int CULL, bool REC>
 RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LDS uint32_t* rec, int32_t e, DEntity ent,
                             V3 o, V3 d, int32_t medium, Closest* best, unsigned long long* stats) {
     if ((RRT_ABL & 4) && ent.kind == 0) return;
     if ((RRT_ABL & 2) && ent.kind != 0) return;
     if (ent.kind == 0) {
         double t;
-        const DSphere S = rec ? lds_uniform<DSphere>(rec + 2) : sc.spheres[ent.index];
+        DSphere S;
+        if constexpr (REC) S = lds_uniform<DSphere>(rec + 2);
+        else S = sc.spheres[ent.index];
         const bool got = (e == medium) ? sphere_collide_inside(S, o, d, &t) : sphere_collide(S, o, d, &t);
         if (got) {
             const V3 pos = o + d * t;                  // sphere.rs:39
@@ -580,7 +589,9 @@ RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LD
             if (dist < best->dist) { best->dist = dist; best->t = t; best->ent = e; best->entry = -1; }
         }
     } else {
-        const DMesh M = rec ? lds_uniform<DMesh>(rec + 2) : sc.meshes[ent.index];
+        DMesh M;
+        if constexpr (REC) M = lds_uniform<DMesh>(rec + 2);
+        else M = sc.meshes[ent.index];
         LeafBest h;
         mesh_collide<CULL>(M, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, &h, stats);
         // same |pos - origin|^2 as the leaf-level metric (kdtree.rs:206 == tracer.rs:184)
@@ -618,7 +629,7 @@ RRT_DEV void group_collide(const DScene& sc, const DGroup& G, const DNodeI* lnod
             const int32_t e = members[lr.first + k];
             DEntity ent = sc.ents[e];
             ent.kind &= ~kEntityMember;            // 0 sphere or 1 mesh (rrt_add_group admits nothing else)
-            entity_collide<CULL>(sc, lnodes, nullptr, e, ent, o, d, medium, &best, stats);   // e differs per lane
+            entity_collide<CULL, false>(sc, lnodes, nullptr, e, ent, o, d, medium, &best, stats);   // e differs per lane
         }
         if (best.ent >= 0) {
             *out = best;
@@ -641,19 +652,27 @@ RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, 
     const DNodeI* lnodes = lds.nodes;
     best->dist = kF64Max; best->t = 0.0; best->ent = -1; best->entry = -1;
     for (int32_t e = 0; e < sc.n_ents; ++e) {
-        const RRT_LDS uint32_t* rec = lds.ents ? lds.ents + e * kEntRec : nullptr;
-        const DEntity ent = rec ? lds_uniform<DEntity>(rec) : sc.ents[e];
+        const RRT_LDS uint32_t* rec = nullptr;
+        DEntity ent;
+        if constexpr (LDS::kSmall) {
+            rec = lds.ents + e * kEntRec;
+            ent = lds_uniform<DEntity>(rec);
+        } else {
+            ent = sc.ents[e];
+        }
         if (GROUPS) {
             if (ent.kind & kEntityMember) continue;
             if (ent.kind == 2) {
-                const DGroup G = rec ? lds_uniform<DGroup>(rec + 2) : sc.groups[ent.index];
+                DGroup G;
+                if constexpr (LDS::kSmall) G = lds_uniform<DGroup>(rec + 2);
+                else G = sc.groups[ent.index];
                 Closest h;
                 group_collide<CULL>(sc, G, lnodes, o, d, medium, &h, stats);
                 if (h.ent >= 0 && h.dist < best->dist) *best = h;
                 continue;
             }
         }
-        entity_collide<CULL>(sc, lnodes, rec, e, ent, o, d, medium, best, stats);
+        entity_collide<CULL, LDS::kSmall>(sc, lnodes, rec, e, ent, o, d, medium, best, stats);
     }
 }
 
@@ -669,7 +688,7 @@ RRT_DEV void finish_hit(const DScene& sc, LDS lds, V3 o, V3 d, const Closest& c,
     if (!h->hit) return;
     h->t = c.t;
     h->pos = o + d * c.t;
-    if (lds.ents) {
+    if constexpr (LDS::kSmall) {
         const RRT_LDS uint32_t* rec = lds.ents + c.ent * kEntRec;
         h->sphere = ((int32_t)rec[0] & ~kEntityMember) == 0;
         if (h->sphere) {
@@ -685,28 +704,28 @@ RRT_DEV void finish_hit(const DScene& sc, LDS lds, V3 o, V3 d, const Closest& c,
             h->normal = ld3g(as_global(nrm) + 3 * (size_t)id);
             h->mat = lds_field<int32_t>(rec, 8 + offsetof(DMesh, material));
         }
-        return;
-    }
-    DEntity ent = sc.ents[c.ent];
-    ent.kind &= ~kEntityMember;
-    h->sphere = ent.kind == 0;
-    if (ent.kind == 0) {
-        const DSphere* S = sc.spheres + ent.index;
-        h->normal = normalize(h->pos - ld3(S->c));
-        h->mat = S->material;
     } else {
-        const DMesh* M = sc.meshes + ent.index;
-        const int32_t id = as_global(M->leaf_refs)[c.entry];
-        h->tri = id;
-        h->normal = ld3g(as_global(M->normals) + 3 * (size_t)id);
-        h->mat = M->material;
+        DEntity ent = sc.ents[c.ent];
+        ent.kind &= ~kEntityMember;
+        h->sphere = ent.kind == 0;
+        if (ent.kind == 0) {
+            const DSphere* S = sc.spheres + ent.index;
+            h->normal = normalize(h->pos - ld3(S->c));
+            h->mat = S->material;
+        } else {
+            const DMesh* M = sc.meshes + ent.index;
+            const int32_t id = as_global(M->leaf_refs)[c.entry];
+            h->tri = id;
+            h->normal = ld3g(as_global(M->normals) + 3 * (size_t)id);
+            h->mat = M->material;
+        }
     }
 }
 
 template <class LDS>
 RRT_DEV DMaterial load_material(const DScene& sc, LDS lds, int32_t mat) {
-    if (lds.mats) return lds_field<DMaterial>(lds.mats + mat * (int32_t)(sizeof(DMaterial) / 4), 0);
-    return sc.mats[mat];
+    if constexpr (LDS::kSmall) return lds_field<DMaterial>(lds.mats + mat * (int32_t)(sizeof(DMaterial) / 4), 0);
+    else return sc.mats[mat];
 }
 
 // texel / 255.0 (cubemap.rs:70-74) for the 256 possible texel values, divided at compile time
@@ -839,6 +858,19 @@ RRT_DEV void continuation(const DFrame& fr, const DMaterial& m, V3 pos, V3 n, V3
     *rd = normalize(nn + sp);
 }
 
+// Path-indexed work arrays are addressed as (uniform base) + (32-bit byte offset of the lane): the
+// base of a component / level is scalar arithmetic and the lane's offset one VGPR shared by every
+// access, where 64-bit indices cost a 64-bit VALU add per access and an SGPR-pair reload for each.
+// plan_frame keeps 8 * (paths per batch) below 2^32.
+template <class T>
+RRT_DEV T& at_off(T* base, uint32_t byte_off) { return *(T*)((char*)base + byte_off); }
+RRT_DEV void st3(double* base, uint64_t P, uint32_t off8, V3 v) {
+    at_off(base, off8) = v.x; at_off(base + P, off8) = v.y; at_off(base + 2 * P, off8) = v.z;
+}
+RRT_DEV V3 ld3s(const double* base, uint64_t P, uint32_t off8) {
+    return mk(at_off(base, off8), at_off(base + P, off8), at_off(base + 2 * P, off8));
+}
+
 // Wave-aggregated queue append: one atomic per wave.
 RRT_DEV uint32_t queue_slot(uint32_t* counter, bool want) {
     const unsigned long long mask = __ballot(want);
@@ -929,6 +961,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
                          uint32_t pixel, uint32_t sample) {
     const uint64_t P = wk.cap;
+    const uint32_t path8 = path * 8u;
     const bool aov = sample == 0u;
     bool cont = false;
     V3 ro = mk(0., 0., 0.), rd = mk(0., 0., 0.);
@@ -952,10 +985,9 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             shade_direct(sc, lds, m, d, h.normal, &A, &Pm);
             cont = !(bounce > fr.max_bounce) && !(fr.prune && m.mixR == 0.0);
             if (cont) {
-                const size_t r = (size_t)bounce * 3 * P + path;
-                wk.recA[r] = A.x; wk.recA[r + P] = A.y; wk.recA[r + 2 * P] = A.z;
-                wk.recP[r] = Pm.x; wk.recP[r + P] = Pm.y; wk.recP[r + 2 * P] = Pm.z;
-                wk.recR[(size_t)bounce * P + path] = m.mixR;
+                st3(wk.recA + (size_t)bounce * 3 * P, P, path8, A);
+                st3(wk.recP + (size_t)bounce * 3 * P, P, path8, Pm);
+                at_off(wk.recR + (size_t)bounce * P, path8) = m.mixR;
                 continuation(fr, m, h.pos, h.normal, d, h.sphere, ent, bounce, pixel, sample, &ro, &rd, &medium);
             } else {
                 col = A + Pm;   // Reflection returned None (reflection.rs:26-28) or was pruned
@@ -969,10 +1001,9 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             // and the bounce kernel lives on memory latency (22 % VALU-busy), so they should overlap.
             CNT(8);
             const uint32_t k = bounce - 1u;
-            const size_t r = (size_t)k * 3 * P + path;
-            const double mr = wk.recR[(size_t)k * P + path];
-            const V3 A = mk(wk.recA[r], wk.recA[r + P], wk.recA[r + 2 * P]);
-            const V3 Pm = mk(wk.recP[r], wk.recP[r + P], wk.recP[r + 2 * P]);
+            const double mr = at_off(wk.recR + (size_t)k * P, path8);
+            const V3 A = ld3s(wk.recA + (size_t)k * 3 * P, P, path8);
+            const V3 Pm = ld3s(wk.recP + (size_t)k * 3 * P, P, path8);
             col = sky_color(sc, lds, d);
             col = (A + col * mr) + Pm;
             fold_from = k;
@@ -981,23 +1012,21 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             CNT(10);
             // fold the enclosing casts: final = (A + R*mixR) + Pm  (tracer.rs:194-202)
             for (uint32_t k = fold_from; k-- > 0;) {
-                const size_t r = (size_t)k * 3 * P + path;
-                const double mr = wk.recR[(size_t)k * P + path];
-                const V3 A = mk(wk.recA[r], wk.recA[r + P], wk.recA[r + 2 * P]);
-                const V3 Pm = mk(wk.recP[r], wk.recP[r + P], wk.recP[r + 2 * P]);
+                const double mr = at_off(wk.recR + (size_t)k * P, path8);
+                const V3 A = ld3s(wk.recA + (size_t)k * 3 * P, P, path8);
+                const V3 Pm = ld3s(wk.recP + (size_t)k * 3 * P, P, path8);
                 col = (A + col * mr) + Pm;
             }
-            if (!(RRT_ABL & 16) || col.x == 12345.678) {
-            wk.samp[path] = col.x; wk.samp[path + P] = col.y; wk.samp[path + 2 * P] = col.z; }
+            if (!(RRT_ABL & 16) || col.x == 12345.678) st3(wk.samp, P, path8, col);
         }
     }
     const uint32_t slot = queue_slot(&wk.q_count[bounce + 1], cont);
     if (cont) {
         const DQueue& q = wk.q[(bounce + 1) & 1];
-        q.o[slot] = ro.x; q.o[slot + P] = ro.y; q.o[slot + 2 * P] = ro.z;
-        q.d[slot] = rd.x; q.d[slot + P] = rd.y; q.d[slot + 2 * P] = rd.z;
-        q.path[slot] = path;
-        q.medium[slot] = medium;
+        st3(q.o, P, slot * 8u, ro);
+        st3(q.d, P, slot * 8u, rd);
+        at_off(q.path, slot * 4u) = path;
+        at_off(q.medium, slot * 4u) = medium;
     }
 }
 
@@ -1011,8 +1040,9 @@ __host__ __device__ inline uint32_t lds_layout_bytes(const DScene& sc) {
 
 // Fills the block's LDS (all threads; ends with a barrier): the descent array of scene.lds_mesh and,
 // after it, the entity records.  Either part may be absent (see DScene::lds_mesh / lds_ents).
-RRT_DEV Staged stage_scene(const DScene& sc, const DFrame& fr, unsigned char* smem) {
-    Staged st{nullptr, nullptr, nullptr, nullptr, nullptr};
+template <bool SMALL>
+RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned char* smem) {
+    StagedT<SMALL> st{nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t off = 0;
     if (sc.lds_mesh >= 0) {
         const DMesh M = sc.meshes[sc.lds_mesh];
@@ -1033,7 +1063,7 @@ RRT_DEV Staged stage_scene(const DScene& sc, const DFrame& fr, unsigned char* sm
         st.nodes = (const DNodeI*)smem;
         off = (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI);
     }
-    if (sc.lds_ents) {
+    if constexpr (SMALL) {
         RRT_LDS uint32_t* tab = (RRT_LDS uint32_t*)(smem + off);
         for (int32_t i = threadIdx.x; i < sc.n_ents * kEntRec; i += blockDim.x) {
             const int32_t e = i / kEntRec, w = i % kEntRec;
@@ -1052,7 +1082,7 @@ RRT_DEV Staged stage_scene(const DScene& sc, const DFrame& fr, unsigned char* sm
         st.ents = tab;
         off += (uint32_t)sc.n_ents * (uint32_t)kEntRec * 4u;
     }
-    if (sc.lds_mats > 0) {
+    if constexpr (SMALL) {
         RRT_LDS uint32_t* tab = (RRT_LDS uint32_t*)(smem + off);
         const uint32_t* src = (const uint32_t*)sc.mats;
         const int32_t n = sc.lds_mats * (int32_t)(sizeof(DMaterial) / 4);
@@ -1095,10 +1125,10 @@ RRT_DEV Staged stage_scene(const DScene& sc, const DFrame& fr, unsigned char* sm
 
 // Persistent blocks: block b takes path tiles b, b + grid, ... (neighbouring tiles, which cost
 // about the same, go to different blocks), so the LDS staging is paid once per block.
-template <int CULL, bool GROUPS>
+template <int CULL, bool GROUPS, bool SMALL>
 __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const Staged lds = stage_scene(sc, fr, smem);
+    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem);
     const uint32_t n_chunks = (uint32_t)(((uint64_t)fr.ns * fr.npx_local) >> 8);   // 256 paths per chunk, exact
 #if RRT_XCD_ORDER
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes the tiles
@@ -1135,7 +1165,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
 // more than an order of magnitude (a reflection that leaves the UFO at once vs. one that walks a
 // dozen leaves inside it); with one fixed 64-ray slice per wave and round, a block kept its LDS and
 // register slots until its slowest wave was done (measured: 2.4 of 4 waves/SIMD resident).
-template <int CULL, bool GROUPS>
+template <int CULL, bool GROUPS, bool SMALL>
 __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = wk.q_count[bounce];
@@ -1148,7 +1178,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
     const uint32_t my_units = (n_units - blockIdx.x + gridDim.x - 1u) / gridDim.x;
     RRT_LDS uint32_t* next_unit = (RRT_LDS uint32_t*)(smem + lds_layout_bytes(sc));
     if (threadIdx.x == 0) *next_unit = 0u;
-    const Staged lds = stage_scene(sc, fr, smem);   // ends with the barrier that also publishes *next_unit
+    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem);   // ends with the barrier that also publishes *next_unit
     const uint64_t P = wk.cap;
     const DQueue& q = wk.q[bounce & 1];
     const uint32_t lane = threadIdx.x & 63u;
@@ -1163,10 +1193,10 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
         uint32_t path = 0, pixel = 0, sample = 0;
         int32_t medium = -1;
         if (active) {
-            o = mk(q.o[i], q.o[i + P], q.o[i + 2 * P]);
-            d = mk(q.d[i], q.d[i + P], q.d[i + 2 * P]);
-            path = q.path[i];
-            medium = q.medium[i];
+            o = ld3s(q.o, P, i * 8u);
+            d = ld3s(q.d, P, i * 8u);
+            path = at_off(q.path, i * 4u);
+            medium = at_off(q.medium, i * 4u);
             // the RNG stream of the diffuse lobe is keyed by the global pixel and sample of the path
             const uint32_t s_local = path / fr.npx_local;
             uint32_t x = 0, y = 0;
@@ -1321,15 +1351,23 @@ inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) 
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
     const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
     const uint32_t grid = (uint32_t)(chunks < trace_grid() ? chunks : trace_grid());
-    auto k = sc.n_groups > 0
-                 ? (sc.cull_mode == 0 ? k_wave_primary<0, true> : sc.cull_mode == 1 ? k_wave_primary<1, true> : k_wave_primary<2, true>)
-                 : (sc.cull_mode == 0 ? k_wave_primary<0, false> : sc.cull_mode == 1 ? k_wave_primary<1, false> : k_wave_primary<2, false>);
+    const auto pick = [&](auto g, auto sm) {
+        constexpr bool G = decltype(g)::value, S = decltype(sm)::value;
+        return sc.cull_mode == 0 ? k_wave_primary<0, G, S> : sc.cull_mode == 1 ? k_wave_primary<1, G, S> : k_wave_primary<2, G, S>;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    auto k = sc.n_groups > 0 ? (sc.lds_ents ? pick(T{}, T{}) : pick(T{}, F{})) : (sc.lds_ents ? pick(F{}, T{}) : pick(F{}, F{}));
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, d_ids, d_t);
 }
 void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream) {
-    auto k = sc.n_groups > 0
-                 ? (sc.cull_mode == 0 ? k_wave_bounce<0, true> : sc.cull_mode == 1 ? k_wave_bounce<1, true> : k_wave_bounce<2, true>)
-                 : (sc.cull_mode == 0 ? k_wave_bounce<0, false> : sc.cull_mode == 1 ? k_wave_bounce<1, false> : k_wave_bounce<2, false>);
+    const auto pick = [&](auto g, auto sm) {
+        constexpr bool G = decltype(g)::value, S = decltype(sm)::value;
+        return sc.cull_mode == 0 ? k_wave_bounce<0, G, S> : sc.cull_mode == 1 ? k_wave_bounce<1, G, S> : k_wave_bounce<2, G, S>;
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    auto k = sc.n_groups > 0 ? (sc.lds_ents ? pick(T{}, T{}) : pick(T{}, F{})) : (sc.lds_ents ? pick(F{}, T{}) : pick(F{}, F{}));
     hipLaunchKernelGGL(k, dim3(bounce_grid()), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
 }
 void launch_accumulate(const DWork& wk, const DFrame& fr, void* stream) {
