@@ -123,7 +123,7 @@ struct rrt_scene {
     rrt::DScene dscene{};
 
     // work buffers
-    DevBuf w_qo[2], w_qd[2], w_qpath[2], w_qmed[2], w_qcount, w_recA, w_recP, w_recR, w_samp, w_accum, w_stats;
+    DevBuf w_q[2], w_qcount, w_rec, w_samp, w_accum, w_stats;
     DevBuf w_ids, w_t, w_color, w_rgb;  // staging for the host-output render
 
     // timing of the last render
@@ -398,8 +398,8 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
     uint64_t max_spp = s->work_budget / ((uint64_t)bpp * fr.npx_local);
     if (st->batch_spp) max_spp = st->batch_spp;
     if (max_spp == 0) return fail(RRT_E_NOMEM, "work budget too small for one sample per pixel (rrt_set_work_budget)");
-    // keep a path's byte offset in the f64 work arrays (8 * path id) in 32 bits: the kernels address them that way
-    max_spp = std::min<uint64_t>(max_spp, 0x1fffffffull / fr.npx_local);
+    // keep a path's byte offset in the work arrays (56 * path id) in 32 bits: the kernels address them that way
+    max_spp = std::min<uint64_t>(max_spp, (0xffffffffull / (rrt::kRecDoubles * 8)) / fr.npx_local);
     if (max_spp == 0) return fail(RRT_E_NOMEM, "frame too large");
     out->n_batches = (uint32_t)((st->spp + max_spp - 1) / max_spp);
     out->batch_spp = (st->spp + out->n_batches - 1) / out->n_batches;
@@ -421,26 +421,16 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
 int ensure_work(rrt_scene* s, const FramePlan& pl, rrt::DWork* wk) {
     const uint64_t P = pl.cap;
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(s->w_qo[i].ensure(P * 3 * 8));
-        HIP_TRY(s->w_qd[i].ensure(P * 3 * 8));
-        HIP_TRY(s->w_qpath[i].ensure(P * 4));
-        wk->q[i].o = s->w_qo[i].as<double>();
-        wk->q[i].d = s->w_qd[i].as<double>();
-        HIP_TRY(s->w_qmed[i].ensure(P * 4));
-        wk->q[i].path = s->w_qpath[i].as<uint32_t>();
-        wk->q[i].medium = s->w_qmed[i].as<int32_t>();
+        HIP_TRY(s->w_q[i].ensure(P * rrt::kRecDoubles * 8));
+        wk->q[i] = s->w_q[i].as<double>();
     }
     HIP_TRY(s->w_qcount.ensure((rrt::kMaxLevels + 1) * 4));
-    HIP_TRY(s->w_recA.ensure(P * 3 * 8 * pl.levels));
-    HIP_TRY(s->w_recP.ensure(P * 3 * 8 * pl.levels));
-    HIP_TRY(s->w_recR.ensure(P * 8 * pl.levels));
+    HIP_TRY(s->w_rec.ensure(P * rrt::kRecDoubles * 8 * pl.levels));
     HIP_TRY(s->w_samp.ensure(P * 3 * 8));
     HIP_TRY(s->w_accum.ensure((size_t)pl.fr.npx_local * 3 * 8));
     HIP_TRY(s->w_stats.ensure(8 * 8));
     wk->q_count = s->w_qcount.as<uint32_t>();
-    wk->recA = s->w_recA.as<double>();
-    wk->recP = s->w_recP.as<double>();
-    wk->recR = s->w_recR.as<double>();
+    wk->rec = s->w_rec.as<double>();
     wk->samp = s->w_samp.as<double>();
     wk->accum = s->w_accum.as<double>();
     wk->stats = s->w_stats.as<unsigned long long>();

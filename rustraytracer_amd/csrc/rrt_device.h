@@ -141,22 +141,15 @@ constexpr int32_t kMaxLdsEnts = 64;      // 128 B of LDS per entity
 constexpr int32_t kMaxLdsMats = 64;      // 72 B of LDS per material
 constexpr int32_t kMaxLdsNodes = 3072;   // 48 KB of LDS per 256-thread block at most
 
-// Ray queue, SoA.  cap entries each.
-struct DQueue {
-    double* o;        // [3][cap]
-    double* d;        // [3][cap]
-    uint32_t* path;   // [cap]
-    int32_t* medium;  // [cap] sphere entity the ray travels inside, -1 = none
-};
-
-// Wavefront work buffers for one batch of P paths.
+// Wavefront work buffers for one batch of P paths.  Records are AoS, kRecDoubles f64 (56 B) each:
+//   queue entry  {o.xyz, d.xyz, (u32 path, i32 medium)}   medium = sphere entity the ray travels inside, -1 = none
+//   level record {A.xyz = color*ambient + L*mixL, Pm.xyz = P*mixP, mixR}
+constexpr int kRecDoubles = 7;
 struct DWork {
-    DQueue q[2];
+    double* q[2];        // [P][7]          ray queues (read / written alternately by the bounce levels)
     uint32_t* q_count;   // [kMaxLevels + 1] entries used per bounce level
-    double* recA;        // [levels][3][P]  color*ambient + L*mixL
-    double* recP;        // [levels][3][P]  P*mixP
-    double* recR;        // [levels][P]     mixR
-    double* samp;        // [3][P]          finished per-sample colour
+    double* rec;         // [levels][P][7]  shading records of the continuing casts
+    double* samp;        // [P][3]          finished per-sample colour
     double* accum;       // [3][npx_local]  running sum over samples
     unsigned long long* stats;  // [0] rays traced, [1] traversal overflows
     uint64_t cap;        // P

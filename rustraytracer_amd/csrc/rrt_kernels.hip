@@ -858,17 +858,28 @@ RRT_DEV void continuation(const DFrame& fr, const DMaterial& m, V3 pos, V3 n, V3
     *rd = normalize(nn + sp);
 }
 
-// Path-indexed work arrays are addressed as (uniform base) + (32-bit byte offset of the lane): the
-// base of a component / level is scalar arithmetic and the lane's offset one VGPR shared by every
-// access, where 64-bit indices cost a 64-bit VALU add per access and an SGPR-pair reload for each.
-// plan_frame keeps 8 * (paths per batch) below 2^32.
+// Path-indexed work arrays hold one record per path (AoS: kRecDoubles f64 per level record and per
+// queue entry, 3 per sample colour) and are addressed as (uniform base) + (32-bit byte offset of the
+// lane) + immediate: one scalar base per array and one VGPR offset serve all fields of a record.
+// With one array per field (SoA) every access carried its own 64-bit address and base pointer --
+// 15 SGPR pairs for the stores of a continuing path, in a kernel that is short of SGPRs.
+// plan_frame keeps 56 * (paths per batch) below 2^32.
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <class T>
-RRT_DEV T& at_off(T* base, uint32_t byte_off) { return *(T*)((char*)base + byte_off); }
-RRT_DEV void st3(double* base, uint64_t P, uint32_t off8, V3 v) {
-    at_off(base, off8) = v.x; at_off(base + P, off8) = v.y; at_off(base + 2 * P, off8) = v.z;
+RRT_DEV T& at_off(double* base, uint32_t byte_off) { return *(T*)((char*)base + byte_off); }
+// level record {A.xyz, Pm.xyz, mixR}
+RRT_DEV void st_rec(double* level_base, uint32_t off, V3 A, V3 Pm, double mixR) {
+    at_off<f64x2>(level_base, off) = f64x2{A.x, A.y};
+    at_off<f64x2>(level_base, off + 16u) = f64x2{A.z, Pm.x};
+    at_off<f64x2>(level_base, off + 32u) = f64x2{Pm.y, Pm.z};
+    at_off<double>(level_base, off + 48u) = mixR;
 }
-RRT_DEV V3 ld3s(const double* base, uint64_t P, uint32_t off8) {
-    return mk(at_off(base, off8), at_off(base + P, off8), at_off(base + 2 * P, off8));
+RRT_DEV void ld_rec(double* level_base, uint32_t off, V3* A, V3* Pm, double* mixR) {
+    const f64x2 a = at_off<f64x2>(level_base, off), b = at_off<f64x2>(level_base, off + 16u),
+                c = at_off<f64x2>(level_base, off + 32u);
+    *mixR = at_off<double>(level_base, off + 48u);
+    *A = mk(a.x, a.y, b.x);
+    *Pm = mk(b.y, c.x, c.y);
 }
 
 // Wave-aggregated queue append: one atomic per wave.
@@ -961,7 +972,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
                          uint32_t pixel, uint32_t sample) {
     const uint64_t P = wk.cap;
-    const uint32_t path8 = path * 8u;
+    const uint32_t rec_off = path * (uint32_t)(kRecDoubles * 8);
     const bool aov = sample == 0u;
     bool cont = false;
     V3 ro = mk(0., 0., 0.), rd = mk(0., 0., 0.);
@@ -985,9 +996,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             shade_direct(sc, lds, m, d, h.normal, &A, &Pm);
             cont = !(bounce > fr.max_bounce) && !(fr.prune && m.mixR == 0.0);
             if (cont) {
-                st3(wk.recA + (size_t)bounce * 3 * P, P, path8, A);
-                st3(wk.recP + (size_t)bounce * 3 * P, P, path8, Pm);
-                at_off(wk.recR + (size_t)bounce * P, path8) = m.mixR;
+                st_rec(wk.rec + (size_t)bounce * kRecDoubles * P, rec_off, A, Pm, m.mixR);
                 continuation(fr, m, h.pos, h.normal, d, h.sphere, ent, bounce, pixel, sample, &ro, &rd, &medium);
             } else {
                 col = A + Pm;   // Reflection returned None (reflection.rs:26-28) or was pruned
@@ -1001,9 +1010,9 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             // and the bounce kernel lives on memory latency (22 % VALU-busy), so they should overlap.
             CNT(8);
             const uint32_t k = bounce - 1u;
-            const double mr = at_off(wk.recR + (size_t)k * P, path8);
-            const V3 A = ld3s(wk.recA + (size_t)k * 3 * P, P, path8);
-            const V3 Pm = ld3s(wk.recP + (size_t)k * 3 * P, P, path8);
+            double mr;
+            V3 A, Pm;
+            ld_rec(wk.rec + (size_t)k * kRecDoubles * P, rec_off, &A, &Pm, &mr);
             col = sky_color(sc, lds, d);
             col = (A + col * mr) + Pm;
             fold_from = k;
@@ -1012,21 +1021,26 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             CNT(10);
             // fold the enclosing casts: final = (A + R*mixR) + Pm  (tracer.rs:194-202)
             for (uint32_t k = fold_from; k-- > 0;) {
-                const double mr = at_off(wk.recR + (size_t)k * P, path8);
-                const V3 A = ld3s(wk.recA + (size_t)k * 3 * P, P, path8);
-                const V3 Pm = ld3s(wk.recP + (size_t)k * 3 * P, P, path8);
+                double mr;
+                V3 A, Pm;
+                ld_rec(wk.rec + (size_t)k * kRecDoubles * P, rec_off, &A, &Pm, &mr);
                 col = (A + col * mr) + Pm;
             }
-            if (!(RRT_ABL & 16) || col.x == 12345.678) st3(wk.samp, P, path8, col);
+            if (!(RRT_ABL & 16) || col.x == 12345.678) {
+                at_off<f64x2>(wk.samp, path * 24u) = f64x2{col.x, col.y};
+                at_off<double>(wk.samp, path * 24u + 16u) = col.z;
+            }
         }
     }
     const uint32_t slot = queue_slot(&wk.q_count[bounce + 1], cont);
     if (cont) {
-        const DQueue& q = wk.q[(bounce + 1) & 1];
-        st3(q.o, P, slot * 8u, ro);
-        st3(q.d, P, slot * 8u, rd);
-        at_off(q.path, slot * 4u) = path;
-        at_off(q.medium, slot * 4u) = medium;
+        // queue entry {o.xyz, d.xyz, (path, medium)}
+        double* q = wk.q[(bounce + 1) & 1];
+        const uint32_t off = slot * (uint32_t)(kRecDoubles * 8);
+        at_off<f64x2>(q, off) = f64x2{ro.x, ro.y};
+        at_off<f64x2>(q, off + 16u) = f64x2{ro.z, rd.x};
+        at_off<f64x2>(q, off + 32u) = f64x2{rd.y, rd.z};
+        at_off<uint2>(q, off + 48u) = make_uint2(path, (uint32_t)medium);
     }
 }
 
@@ -1180,7 +1194,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
     if (threadIdx.x == 0) *next_unit = 0u;
     const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem);   // ends with the barrier that also publishes *next_unit
     const uint64_t P = wk.cap;
-    const DQueue& q = wk.q[bounce & 1];
+    double* q = wk.q[bounce & 1];
     const uint32_t lane = threadIdx.x & 63u;
     for (;;) {
         uint32_t u = 0u;
@@ -1193,10 +1207,13 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
         uint32_t path = 0, pixel = 0, sample = 0;
         int32_t medium = -1;
         if (active) {
-            o = ld3s(q.o, P, i * 8u);
-            d = ld3s(q.d, P, i * 8u);
-            path = at_off(q.path, i * 4u);
-            medium = at_off(q.medium, i * 4u);
+            const uint32_t off = i * (uint32_t)(kRecDoubles * 8);
+            const f64x2 a = at_off<f64x2>(q, off), b = at_off<f64x2>(q, off + 16u), c = at_off<f64x2>(q, off + 32u);
+            const uint2 pm = at_off<uint2>(q, off + 48u);
+            o = mk(a.x, a.y, b.x);
+            d = mk(b.y, c.x, c.y);
+            path = pm.x;
+            medium = (int32_t)pm.y;
             // the RNG stream of the diffuse lobe is keyed by the global pixel and sample of the path
             const uint32_t s_local = path / fr.npx_local;
             uint32_t x = 0, y = 0;
@@ -1218,8 +1235,8 @@ __global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr) {
     V3 acc = mk(0., 0., 0.);
     if (fr.s0 != 0u) acc = mk(wk.accum[lp], wk.accum[lp + N], wk.accum[lp + 2 * (size_t)N]);
     for (uint32_t s = 0; s < fr.ns; ++s) {
-        const size_t p = (size_t)s * N + pp;
-        const V3 c = mk(wk.samp[p], wk.samp[p + P], wk.samp[p + 2 * P]);
+        const size_t p = 3 * ((size_t)s * N + pp);
+        const V3 c = mk(wk.samp[p], wk.samp[p + 1], wk.samp[p + 2]);
         acc = (fr.s0 + s == 0u) ? c : acc + c;
     }
     wk.accum[lp] = acc.x; wk.accum[lp + N] = acc.y; wk.accum[lp + 2 * (size_t)N] = acc.z;
