@@ -461,9 +461,14 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, Leaf
             return;
         }
         CNT(7);
+        // the six ropes travel with the box (one round trip); the face picks among registers
+        typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
         const V3 mn = ld3g(L->mn), mx = ld3g(L->mx);
+        const i32x2 r01 = *(const RRT_GLOBAL i32x2*)&L->rope[0], r23 = *(const RRT_GLOBAL i32x2*)&L->rope[2],
+                    r45 = *(const RRT_GLOBAL i32x2*)&L->rope[4];
         point = box_exit(mn, mx, point, d, inv) + d * 0.001;
-        const int32_t nb = L->rope[get_plane(point, mn, mx)];
+        const int pl = get_plane(point, mn, mx);
+        const int32_t nb = pl == 0 ? r01.x : pl == 1 ? r01.y : pl == 2 ? r23.x : pl == 3 ? r23.y : pl == 4 ? r45.x : r45.y;
         if (nb < 0) return;
         lr = find_point(M.nodes, M.boxes, lnodes, nb, point);
     }
@@ -997,7 +1002,17 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             cont = !(bounce > fr.max_bounce) && !(fr.prune && m.mixR == 0.0);
             if (cont) {
                 st_rec(wk.rec + (size_t)bounce * kRecDoubles * P, rec_off, A, Pm, m.mixR);
-                continuation(fr, m, h.pos, h.normal, d, h.sphere, ent, bounce, pixel, sample, &ro, &rd, &medium);
+                uint32_t kp = pixel, ks = sample;
+                if (!PRIMARY && m.lobe == 2) {
+                    // the RNG stream of the diffuse lobe is keyed by the global pixel and sample of the path
+                    // (two integer divisions per lane: only paid by the rays that draw from it)
+                    const uint32_t s_local = path / fr.npx_local;
+                    uint32_t x = 0, y = 0;
+                    local_pixel(fr, path_to_lp(path - s_local * fr.npx_local), &x, &y);
+                    kp = y * fr.width + x;
+                    ks = fr.s0 + s_local;
+                }
+                continuation(fr, m, h.pos, h.normal, d, h.sphere, ent, bounce, kp, ks, &ro, &rd, &medium);
             } else {
                 col = A + Pm;   // Reflection returned None (reflection.rs:26-28) or was pruned
             }
@@ -1144,12 +1159,13 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
     extern __shared__ __align__(16) unsigned char smem[];
     const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem);
     const uint32_t n_chunks = (uint32_t)(((uint64_t)fr.ns * fr.npx_local) >> 8);   // 256 paths per chunk, exact
+    const uint32_t n_tiles = fr.npx_local >> 8;
+    const uint32_t my_in = tile_swz(threadIdx.x);   // this thread's pixel inside every tile it visits
 #if RRT_XCD_ORDER
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes the tiles
     // t = x (mod 8), and its blocks walk them tile-major (all samples of a tile back to back, on
     // neighbouring blocks of the same XCD), so what one sample of a tile pulls in -- its leaves and
     // triangles, the sky texel lines behind it -- is in that L2 for the other samples.
-    const uint32_t n_tiles = fr.npx_local >> 8;
     const bool by_xcd = (gridDim.x & 7u) == 0u && n_tiles >= 8u;
     const uint32_t xcd = blockIdx.x & 7u;
     const uint32_t limit = by_xcd ? ((n_tiles + 7u - xcd) >> 3) * fr.ns : n_chunks;
@@ -1163,10 +1179,13 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
 #else
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
 #endif
+        // chunk = (sample, tile slot): wave-uniform, so the tile's position is scalar arithmetic
         const uint32_t path = chunk * 256u + threadIdx.x;
-        const uint32_t s_local = path / fr.npx_local, lp = path - s_local * fr.npx_local;
-        uint32_t x = 0, y = 0;
-        const bool active = local_pixel(fr, path_to_lp(lp), &x, &y);
+        const uint32_t s_local = chunk / n_tiles, slot = chunk - s_local * n_tiles;
+        const uint32_t tile = slot * fr.tile_world + fr.tile_rank;
+        const uint32_t ty = tile / fr.tiles_x, tx = tile - ty * fr.tiles_x;
+        const uint32_t x = tx * RRT_TILE_W + (my_in & 31u), y = ty * RRT_TILE_H + (my_in >> 5);
+        const bool active = tile < fr.tiles_x * fr.tiles_y && x < fr.width && y < fr.height;
         const uint32_t sample = fr.s0 + s_local;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         if (active) primary_ray(fr, lds, x, y, sample, &o, &d);
@@ -1204,7 +1223,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
         const uint32_t i = (u * gridDim.x + blockIdx.x) * 64u + lane;
         const bool active = i < count;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-        uint32_t path = 0, pixel = 0, sample = 0;
+        uint32_t path = 0;
         int32_t medium = -1;
         if (active) {
             const uint32_t off = i * (uint32_t)(kRecDoubles * 8);
@@ -1214,14 +1233,8 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
             d = mk(b.y, c.x, c.y);
             path = pm.x;
             medium = (int32_t)pm.y;
-            // the RNG stream of the diffuse lobe is keyed by the global pixel and sample of the path
-            const uint32_t s_local = path / fr.npx_local;
-            uint32_t x = 0, y = 0;
-            local_pixel(fr, path_to_lp(path - s_local * fr.npx_local), &x, &y);
-            pixel = y * fr.width + x;
-            sample = fr.s0 + s_local;
         }
-        process_ray<false, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, pixel, sample);
+        process_ray<false, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u);
     }
 }
 
