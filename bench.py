@@ -219,6 +219,7 @@ def main():
             line["metric"] = "Mrays/s (node) %s" % args.config
             line["config"]["n_batches"] = stats["n_batches"]
             line["config"]["level_rays"] = stats["level_rays"]
+            line["config"]["kernel_ms"] = {"k_wave_primary": prim_ms, "k_wave_bounce": bnc_ms, "gpu": stats["gpu_ms"]}
         if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
             nthreads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
             line["cpu_baseline"], cpu_c, prim_c, n_prim = cpu_leg(nthreads)

@@ -1070,10 +1070,10 @@ __host__ __device__ inline uint32_t lds_layout_bytes(const DScene& sc) {
 // Fills the block's LDS (all threads; ends with a barrier): the descent array of scene.lds_mesh and,
 // after it, the entity records.  Either part may be absent (see DScene::lds_mesh / lds_ents).
 template <bool SMALL>
-RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned char* smem) {
+RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned char* smem, bool with_nodes) {
     StagedT<SMALL> st{nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t off = 0;
-    if (sc.lds_mesh >= 0) {
+    if (sc.lds_mesh >= 0 && with_nodes) {
         const DMesh M = sc.meshes[sc.lds_mesh];
         // one 16-byte node per thread and trip, four trips' loads in flight before the first store
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1090,8 +1090,8 @@ RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned 
             if (i3 < n) dst[i3] = v3;
         }
         st.nodes = (const DNodeI*)smem;
-        off = (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI);
     }
+    if (sc.lds_mesh >= 0) off = (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI);
     if constexpr (SMALL) {
         RRT_LDS uint32_t* tab = (RRT_LDS uint32_t*)(smem + off);
         for (int32_t i = threadIdx.x; i < sc.n_ents * kEntRec; i += blockDim.x) {
@@ -1157,7 +1157,7 @@ RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned 
 template <int CULL, bool GROUPS, bool SMALL>
 __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem);
+    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, true);
     const uint32_t n_chunks = (uint32_t)(((uint64_t)fr.ns * fr.npx_local) >> 8);   // 256 paths per chunk, exact
     const uint32_t n_tiles = fr.npx_local >> 8;
     const uint32_t my_in = tile_swz(threadIdx.x);   // this thread's pixel inside every tile it visits
@@ -1211,7 +1211,8 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
     const uint32_t my_units = (n_units - blockIdx.x + gridDim.x - 1u) / gridDim.x;
     RRT_LDS uint32_t* next_unit = (RRT_LDS uint32_t*)(smem + lds_layout_bytes(sc));
     if (threadIdx.x == 0) *next_unit = 0u;
-    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem);   // ends with the barrier that also publishes *next_unit
+    // a block with a single 64-ray unit (the thin last levels) descends from global memory rather than copy the array
+    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, my_units > 1u);   // ends with the barrier that also publishes *next_unit
     const uint64_t P = wk.cap;
     double* q = wk.q[bounce & 1];
     const uint32_t lane = threadIdx.x & 63u;
@@ -1355,14 +1356,14 @@ __global__ void k_selftest(int op, const double* a, const double* b, int64_t n, 
     out[i] = r;
 }
 
-// Persistent grid of the trace kernels: 256 CUs x 32 blocks of 256 threads -- 8 rounds of resident
-// blocks, so the hardware block scheduler evens out the tail (measured: 1024/2048 blocks 3.27 ms,
-// 8192 blocks 3.12 ms per cfg2 frame).  RRT_TRACE_GRID overrides, for tuning.
+// Persistent grid of the trace kernels: 256 CUs x 64 blocks of 256 threads -- 16 rounds of resident
+// blocks, so the hardware block scheduler evens out the tail (measured, primary kernel of a cfg2 frame:
+// 4096 blocks 1.63 ms, 8192 1.51, 16384 1.47, 32768 1.51, 65528 1.64).  RRT_TRACE_GRID overrides, for tuning.
 inline uint32_t trace_grid() {
     static const uint32_t g = [] {
         const char* e = getenv("RRT_TRACE_GRID");
         const long v = e ? atol(e) : 0;
-        return (uint32_t)(v > 0 && v <= 65535 ? v : 256 * 32);
+        return (uint32_t)(v > 0 && v <= 65535 ? v : 256 * 64);
     }();
     return g;
 }
