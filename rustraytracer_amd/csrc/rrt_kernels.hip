@@ -302,7 +302,14 @@ struct CullRay {
     float tmin;     // -(bound on dt)
 };
 
-RRT_DEV CullRay make_cull_ray(const DMesh& M, V3 o, V3 d, V3 inv) {
+// The mesh constants of the cull (DMesh::center .. abs_max) as plain per-lane values: wave-uniform,
+// but they are only ever VALU operands, so they need no SGPRs (and no v_readfirstlane to get there).
+struct CullConst {
+    double center[3];
+    double radius, edge_max, abs_max;
+};
+static_assert(offsetof(DMesh, abs_max) - offsetof(DMesh, center) == 5 * sizeof(double), "DMesh cull constants are contiguous");
+RRT_DEV CullRay make_cull_ray(const CullConst& M, V3 o, V3 d, V3 inv) {
     const double dl = fabs(d.x) + fabs(d.y) + fabs(d.z);                       // >= |d|
     const double R = fabs(o.x - M.center[0]) + fabs(o.y - M.center[1]) + fabs(o.z - M.center[2]) + M.radius;
     const double S = M.edge_max;
@@ -361,7 +368,7 @@ RRT_DEV void leaf_test(const TriData& T, int32_t entry, V3 o, V3 d, LeafBest* b)
 
 // KDTree::collide (kdtree.rs:192-235).  Returns the winning stream entry in out->entry (-1 = miss).
 template <int CULL>
-RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, LeafBest* out,
+RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnodes, V3 o, V3 d, LeafBest* out,
                           unsigned long long* stats) {
     out->entry = -1; out->dist = kF64Max; out->t = 0.0;
     CNT(1);
@@ -375,7 +382,7 @@ RRT_DEV void mesh_collide(const DMesh& M, const DNodeI* lnodes, V3 o, V3 d, Leaf
     point = point + d * 0.01;
     LeafRef lr = find_point(M.nodes, M.boxes, lnodes, 0, point);
     CullRay cr;
-    if (CULL != 0) cr = make_cull_ray(M, o, d, inv);
+    if (CULL != 0) cr = make_cull_ray(K, o, d, inv);
     const RRT_GLOBAL DLeaf* leaves = as_global(M.leaves);
     const RRT_GLOBAL DTri* stream = as_global(M.tris);
     uint32_t visits = 0;
@@ -585,7 +592,7 @@ RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LD
     if (ent.kind == 0) {
         double t;
         DSphere S;
-        if constexpr (REC) S = lds_uniform<DSphere>(rec + 2);
+        if constexpr (REC) S = lds_field<DSphere>(rec + 2, 0);   // VALU operands only: straight from LDS into VGPRs
         else S = sc.spheres[ent.index];
         const bool got = (e == medium) ? sphere_collide_inside(S, o, d, &t) : sphere_collide(S, o, d, &t);
         if (got) {
@@ -595,10 +602,16 @@ RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LD
         }
     } else {
         DMesh M;
-        if constexpr (REC) M = lds_uniform<DMesh>(rec + 2);
-        else M = sc.meshes[ent.index];
+        CullConst K;
+        if constexpr (REC) {
+            M = lds_uniform<DMesh>(rec + 2);      // the array bases become SGPRs; what is not used is never read
+            K = lds_field<CullConst>(rec + 2, offsetof(DMesh, center));
+        } else {
+            M = sc.meshes[ent.index];
+            K = CullConst{{M.center[0], M.center[1], M.center[2]}, M.radius, M.edge_max, M.abs_max};
+        }
         LeafBest h;
-        mesh_collide<CULL>(M, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, &h, stats);
+        mesh_collide<CULL>(M, K, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, &h, stats);
         // same |pos - origin|^2 as the leaf-level metric (kdtree.rs:206 == tracer.rs:184)
         if (h.entry >= 0 && h.dist < best->dist) {
             best->dist = h.dist; best->t = h.t; best->ent = e; best->entry = h.entry;
