@@ -18,4 +18,19 @@ w = csv.DictWriter(open(sys.argv[2], "w"), keep); w.writeheader()
 for r in rows: w.writerow({k: r[k] for k in keep})
 PY
 done
+# bench.py attaches profiles/pmc_traffic.json and profiles/valu_busy.json as it finds them at run time, i.e. the
+# PREVIOUS collection's; re-attach the ones this collection produced so the committed line is self-consistent.
+python3 - profiles/${TAG}_bench.json <<'PY'
+import json, sys
+f = sys.argv[1]
+d = json.load(open(f))
+t = json.load(open("profiles/pmc_traffic.json")).get("k_wave_primary")
+v = json.load(open("profiles/valu_busy.json")).get("k_wave_primary")
+if t:
+    d["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+    d["roofline"]["traffic_source"] = t.get("source")
+if v:
+    d["roofline"]["valu_issue"] = v
+json.dump(d, open(f, "w"))
+PY
 ls -la profiles
