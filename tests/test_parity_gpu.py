@@ -449,6 +449,22 @@ def test_scene_groups_bit_exact(H, O, scenes):
     assert fo["stats"]["rays_traced"] > 0
 
 
+def test_large_entity_count_takes_the_global_memory_kernels(H, O, scenes):
+    """More than 64 entities: the entity table and the materials no longer fit the LDS record area, so the
+    trace kernels of the other template instantiation run (entity / sphere / mesh structs and materials
+    read from global memory).  Flat list and Scene<T> group, cull modes 1 and 2, bit-exact against the oracle."""
+    for grouped in (False, True):
+        g = scenes.many_entity_scene(H.World(device=0), H.loaders, n_spheres=90, seed=11, grouped=grouped)
+        c = scenes.many_entity_scene(O.OracleScene(), O, n_spheres=90, seed=11, grouped=grouped)
+        for mode in (1, 2):
+            g.set_cull_mode(mode)
+            go, co = g.render(480, 270, spp=2, seed=5, max_bounce=3), c.render(480, 270, spp=2, seed=5, max_bounce=3)
+            _same(go, co)
+            assert go["stats"]["cull_violations"] == 0 and go["stats"]["traversal_overflow"] == 0
+        assert go["stats"]["rays_traced"] == int(co["counters"][0])
+        assert len(np.unique(go["ids"][..., 0])) > 50
+
+
 def test_cpp_host_main_rs_writes_bruh_png(golden_dir, tmp_path):
     """examples/main.cpp = src/main.rs restated on the C++ host mirror (include/rrt_host.hpp);
     the PNG it writes through the C ABI must decode to the reference's bruh.png."""
