@@ -26,6 +26,37 @@ def test_library_exports_every_declared_symbol(H):
     assert b"gfx950" in B.lib.rrt_version()
 
 
+def test_rust_binding_source_matches_the_c_abi(H):
+    """bindings/rust/rrt-sys cannot be compiled here (no rustc); what can be checked is checked: every
+    function it declares is exported by librrt.so with the same number of parameters as the C header, and
+    its #[repr(C)] structs list the same fields, in order, with the same widths as the C structs."""
+    from rustraytracer_amd import binding as B
+    rs = open(os.path.join(ROOT, "bindings", "rust", "rrt-sys", "src", "lib.rs")).read()
+    rs = re.sub(r"//[^\n]*", "", rs)
+    hdr = ""
+    for h in ("rrt.h", "rrt_host.h"):
+        hdr += re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", h)).read(), flags=re.S)
+    c_fns = {m.group(1): m.group(2) for m in re.finditer(r"\b(rrt_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", hdr)}
+    rs_fns = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (rrt_[a-z0-9_]+)\s*\(([^)]*)\)", rs)}
+    assert len(rs_fns) >= 30
+    for name, args in rs_fns.items():
+        assert name in c_fns and hasattr(B.lib, name), name
+        n_rs = 0 if not args.strip() else len([a for a in args.split(",") if a.strip()])
+        c_args = c_fns[name].strip()
+        n_c = 0 if c_args in ("", "void") else len(c_args.split(","))
+        assert n_rs == n_c, (name, n_rs, n_c)
+    width = {"u32": 4, "u64": 8, "f64": 8, "i32": 4, "uint32_t": 4, "uint64_t": 8, "double": 8, "int32_t": 4}
+    for st in ("rrt_camera", "rrt_settings", "rrt_stats"):
+        cbody = re.search(r"typedef struct %s \{(.*?)\}" % st, hdr, re.S).group(1)
+        cf = [(m.group(2), width[m.group(1)] * int(m.group(3) or 1))
+              for m in re.finditer(r"(\w+)\s+(\w+)(?:\[(\d+)\])?;", cbody)]
+        rbody = re.search(r"pub struct %s \{(.*?)\}" % st, rs, re.S).group(1)
+        rf = [(m.group(1), width[m.group(3) or m.group(2)] * int(m.group(4) or 1))
+              for m in re.finditer(r"pub (\w+): (?:(\w+)|\[(\w+); (\d+)\]),", rbody)]
+        assert cf == rf and cf, (st, cf, rf)
+        assert sum(w for _, w in cf) == C.sizeof({"rrt_camera": B.Camera, "rrt_settings": B.Settings, "rrt_stats": B.Stats}[st])
+
+
 def test_loaders_agree_with_oracle_side(H, O, scenes):
     for obj, pos, sc in (("ufo_fix.obj", (0, 30, 70), (1, -1, 1)), ("cube.obj", (0, 0, 12), (2, 2, 2))):
         p = os.path.join(scenes.ASSETS, "obj", obj)
