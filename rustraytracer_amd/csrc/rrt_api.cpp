@@ -123,7 +123,7 @@ struct rrt_scene {
     rrt::DScene dscene{};
 
     // work buffers
-    DevBuf w_q[2], w_qcount, w_rec, w_samp, w_accum, w_stats;
+    DevBuf w_q[2], w_qcount, w_rec, w_samp, w_samp32, w_accum, w_stats;
     DevBuf w_ids, w_t, w_color, w_rgb;  // staging for the host-output render
 
     // timing of the last render
@@ -367,7 +367,7 @@ struct FramePlan {
 
 size_t bytes_per_path(uint32_t levels) {
     return (size_t)levels * 7 * 8   // recA + recP + recR
-           + 3 * 8                  // samp
+           + 3 * 8 + 4              // samp, samp32
            + 2 * (6 * 8 + 4 + 4);   // two queues
 }
 
@@ -427,11 +427,13 @@ int ensure_work(rrt_scene* s, const FramePlan& pl, rrt::DWork* wk) {
     HIP_TRY(s->w_qcount.ensure((rrt::kMaxLevels + 1) * 4));
     HIP_TRY(s->w_rec.ensure(P * rrt::kRecDoubles * 8 * pl.levels));
     HIP_TRY(s->w_samp.ensure(P * 3 * 8));
+    HIP_TRY(s->w_samp32.ensure(P * 4));
     HIP_TRY(s->w_accum.ensure((size_t)pl.fr.npx_local * 3 * 8));
     HIP_TRY(s->w_stats.ensure(8 * 8));
     wk->q_count = s->w_qcount.as<uint32_t>();
     wk->rec = s->w_rec.as<double>();
     wk->samp = s->w_samp.as<double>();
+    wk->samp32 = s->w_samp32.as<uint32_t>();
     wk->accum = s->w_accum.as<double>();
     wk->stats = s->w_stats.as<unsigned long long>();
     wk->cap = P;

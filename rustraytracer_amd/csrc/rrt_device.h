@@ -149,7 +149,8 @@ struct DWork {
     double* q[2];        // [P][7]          ray queues (read / written alternately by the bounce levels)
     uint32_t* q_count;   // [kMaxLevels + 1] entries used per bounce level
     double* rec;         // [levels][P][7]  shading records of the continuing casts
-    double* samp;        // [P][3]          finished per-sample colour
+    double* samp;        // [P][3]          finished per-sample colour ...
+    uint32_t* samp32;    // [P]             ... unless this says kSampTexel | sky texel (a primary ray that ended in the sky)
     double* accum;       // [3][npx_local]  running sum over samples
     unsigned long long* stats;  // [0] rays traced, [1] traversal overflows
     uint64_t cap;        // P

@@ -758,9 +758,10 @@ struct By255 {
 __device__ const By255 kBy255{};
 
 // cubemap() + CubemapBehavior::compute (cubemap.rs:84-164, 56-77)
+// The texel cubemap() lands on, packed r | g << 8 | b << 16.
 template <class LDS>
-RRT_DEV V3 sky_color(const DScene& sc, LDS lds, V3 dir) {
-    if (RRT_ABL & 1) return dir;
+RRT_DEV uint32_t sky_texel(const DScene& sc, LDS lds, V3 dir) {
+    if (RRT_ABL & 1) return 0u;
     const double x = dir.x, y = dir.y, z = dir.z;
     const double ax = fabs(x), ay = fabs(y), az = fabs(z);
     const bool xp = x > 0.0, yp = y > 0.0, zp = z > 0.0;
@@ -787,13 +788,20 @@ RRT_DEV V3 sky_color(const DScene& sc, LDS lds, V3 dir) {
     uint32_t px = sat_u32(u * (double)w), py = sat_u32(v * (double)hgt);
     if (px >= w) px = w - 1;
     if (py >= hgt) py = hgt - 1;
-    const uint8_t* p = face + ((size_t)py * w + px) * 3;
-#ifndef RRT_NO_LUT
-    if constexpr (LDS::kStaged) return mk(lds.by255[p[0]], lds.by255[p[1]], lds.by255[p[2]]);
-    return mk(kBy255.v[p[0]], kBy255.v[p[1]], kBy255.v[p[2]]);
-#else
-    return mk((double)p[0] / 255.0, (double)p[1] / 255.0, (double)p[2] / 255.0);
-#endif
+    const RRT_GLOBAL uint8_t* p = as_global(face) + ((size_t)py * w + px) * 3;
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+// CubemapBehavior::compute's rgb / 255.0 (cubemap.rs:70-74) through the 256-entry quotient table
+template <class LDS>
+RRT_DEV V3 texel_color(LDS lds, uint32_t t) {
+    const uint32_t r = t & 255u, g = (t >> 8) & 255u, b = (t >> 16) & 255u;
+    if constexpr (LDS::kStaged) return mk(lds.by255[r], lds.by255[g], lds.by255[b]);
+    return mk(kBy255.v[r], kBy255.v[g], kBy255.v[b]);
+}
+template <class LDS>
+RRT_DEV V3 sky_color(const DScene& sc, LDS lds, V3 dir) {
+    if (RRT_ABL & 1) return dir;
+    return texel_color(lds, sky_texel(sc, lds, dir));
 }
 
 // Direct terms of a hit (tracer.rs:194-202 with lambert.rs:22-45, phong.rs:25-47):
@@ -883,8 +891,9 @@ RRT_DEV void continuation(const DFrame& fr, const DMaterial& m, V3 pos, V3 n, V3
 // 15 SGPR pairs for the stores of a continuing path, in a kernel that is short of SGPRs.
 // plan_frame keeps 56 * (paths per batch) below 2^32.
 typedef double f64x2 __attribute__((ext_vector_type(2)));
-template <class T>
-RRT_DEV T& at_off(double* base, uint32_t byte_off) { return *(T*)((char*)base + byte_off); }
+template <class T, class B>
+RRT_DEV T& at_off(B* base, uint32_t byte_off) { return *(T*)((char*)base + byte_off); }
+constexpr uint32_t kSampTexel = 0x01000000u;   // samp32 tag: the low 24 bits are a sky texel (else: the colour is in samp)
 // level record {A.xyz, Pm.xyz, mixR}
 RRT_DEV void st_rec(double* level_base, uint32_t off, V3 A, V3 Pm, double mixR) {
     at_off<f64x2>(level_base, off) = f64x2{A.x, A.y};
@@ -992,7 +1001,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
     const uint64_t P = wk.cap;
     const uint32_t rec_off = path * (uint32_t)(kRecDoubles * 8);
     const bool aov = sample == 0u;
-    bool cont = false;
+    bool cont = false, compact = false;
     V3 ro = mk(0., 0., 0.), rd = mk(0., 0., 0.);
     if (active) {
         Closest c;
@@ -1030,8 +1039,12 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
                 col = A + Pm;   // Reflection returned None (reflection.rs:26-28) or was pruned
             }
         } else if (PRIMARY) {
+            // A primary ray that ends in the sky (4 of 5 do): its sample colour is texel / 255, so the three
+            // texel bytes ARE the colour -- 4 bytes go to samp32 instead of 24 to samp, and k_accumulate
+            // looks the quotients up.
             CNT(8);
-            col = sky_color(sc, lds, d);
+            at_off<uint32_t>(wk.samp32, path * 4u) = kSampTexel | sky_texel(sc, lds, d);
+            compact = true;
         } else {
             // A bounce ray that leaves the scene ends its path (most do).  Its innermost enclosing
             // record is requested BEFORE the sky texel: both are HBM misses on incoherent addresses,
@@ -1045,7 +1058,8 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             col = (A + col * mr) + Pm;
             fold_from = k;
         }
-        if (!cont) {
+        if (PRIMARY && !compact) at_off<uint32_t>(wk.samp32, path * 4u) = 0u;   // "see samp" (written now or by a bounce level)
+        if (!cont && !compact) {
             CNT(10);
             // fold the enclosing casts: final = (A + R*mixR) + Pm  (tracer.rs:194-202)
             for (uint32_t k = fold_from; k-- > 0;) {
@@ -1254,16 +1268,24 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
 
 // accum[lp] (+)= sum over this batch's samples, in sample order.
 __global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr) {
-    const uint32_t lp = blockIdx.x * 256u + threadIdx.x;
-    if (lp >= fr.npx_local) return;
-    const uint64_t P = wk.cap;
+    __shared__ double by255[256];
+    by255[threadIdx.x] = (double)threadIdx.x / 255.0;          // cubemap.rs:70-74, one IEEE division per thread
+    __syncthreads();
+    const uint32_t lp = blockIdx.x * 256u + threadIdx.x;       // grid = npx_local / 256 exactly
     const uint32_t N = fr.npx_local;
     const uint32_t pp = (lp & ~255u) | tile_unswz(lp & 255u);   // where the trace kernels put this pixel's samples
     V3 acc = mk(0., 0., 0.);
     if (fr.s0 != 0u) acc = mk(wk.accum[lp], wk.accum[lp + N], wk.accum[lp + 2 * (size_t)N]);
     for (uint32_t s = 0; s < fr.ns; ++s) {
-        const size_t p = 3 * ((size_t)s * N + pp);
-        const V3 c = mk(wk.samp[p], wk.samp[p + 1], wk.samp[p + 2]);
+        const size_t q = (size_t)s * N + pp;
+        const uint32_t tag = wk.samp32[q];
+        V3 c;
+        if (tag & kSampTexel) {
+            c = mk(by255[tag & 255u], by255[(tag >> 8) & 255u], by255[(tag >> 16) & 255u]);
+        } else {
+            const size_t p = 3 * q;
+            c = mk(wk.samp[p], wk.samp[p + 1], wk.samp[p + 2]);
+        }
         acc = (fr.s0 + s == 0u) ? c : acc + c;
     }
     wk.accum[lp] = acc.x; wk.accum[lp + N] = acc.y; wk.accum[lp + 2 * (size_t)N] = acc.z;
