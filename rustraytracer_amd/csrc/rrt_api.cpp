@@ -492,9 +492,8 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
             rrt::launch_bounce(s->dscene, wk, fr, bounce, stream);
             HIP_TRY(hipEventRecord(tl->b, stream));
         }
-        rrt::launch_accumulate(wk, fr, stream);
+        rrt::launch_accumulate(wk, fr, b + 1 == pl.n_batches, (uint8_t*)d_rgb8, (double*)d_color, stream);   // the last one resolves
     }
-    rrt::launch_resolve(wk, fr, (uint8_t*)d_rgb8, (double*)d_color, stream);
     HIP_TRY(hipEventRecord(s->ev_end, stream));
     HIP_TRY(hipGetLastError());
     s->have_frame = true;

@@ -172,8 +172,7 @@ struct DFrame {
 // ---- launchers (rrt_kernels.hip); all asynchronous on `stream` ------------
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream);
 void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream);
-void launch_accumulate(const DWork& wk, const DFrame& fr, void* stream);
-void launch_resolve(const DWork& wk, const DFrame& fr, uint8_t* d_rgb8, double* d_color, void* stream);
+void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream);
 void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream);
 void launch_trace_rays(const DScene& sc, const double* d_rays, int64_t n, int32_t* ent, int32_t* tri, double* t,
                        double* pos, double* nrm, unsigned long long* stats, void* stream);

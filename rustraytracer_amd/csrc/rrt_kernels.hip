@@ -1266,8 +1266,28 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork
     }
 }
 
-// accum[lp] (+)= sum over this batch's samples, in sample order.
-__global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr) {
+// mean = sum / spp ; vec_rgb (common.rs:75-81); row-major frame or this rank's compact tile buffer
+RRT_DEV void resolve_pixel(const DFrame& fr, uint32_t lp, V3 sum, uint8_t* d_rgb8, double* d_color) {
+    uint32_t x = 0, y = 0;
+    const bool valid = local_pixel(fr, lp, &x, &y);
+    const double n = (double)fr.spp;
+    V3 mean = mk(0., 0., 0.);
+    if (valid) mean = mk(sum.x / n, sum.y / n, sum.z / n);
+    const uint32_t r = sat_u8(mean.x * 255.0), g = sat_u8(mean.y * 255.0), b = sat_u8(mean.z * 255.0);
+    if (fr.tile_world == 1u) {
+        if (!valid) return;
+        const size_t px = (size_t)y * fr.width + x;
+        if (d_rgb8) { d_rgb8[3 * px] = (uint8_t)r; d_rgb8[3 * px + 1] = (uint8_t)g; d_rgb8[3 * px + 2] = (uint8_t)b; }
+        if (d_color) { d_color[3 * px] = mean.x; d_color[3 * px + 1] = mean.y; d_color[3 * px + 2] = mean.z; }
+    } else if (d_rgb8) {
+        d_rgb8[3 * (size_t)lp] = (uint8_t)r; d_rgb8[3 * (size_t)lp + 1] = (uint8_t)g; d_rgb8[3 * (size_t)lp + 2] = (uint8_t)b;
+    }
+}
+
+// accum[lp] (+)= sum over this batch's samples, in sample order (deterministic: the oracle's loop).
+// FINAL (the frame's last batch): the sum goes straight into the pixel instead of back to accum.
+template <bool FINAL>
+__global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr, uint8_t* d_rgb8, double* d_color) {
     __shared__ double by255[256];
     by255[threadIdx.x] = (double)threadIdx.x / 255.0;          // cubemap.rs:70-74, one IEEE division per thread
     __syncthreads();
@@ -1288,27 +1308,10 @@ __global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr) {
         }
         acc = (fr.s0 + s == 0u) ? c : acc + c;
     }
-    wk.accum[lp] = acc.x; wk.accum[lp + N] = acc.y; wk.accum[lp + 2 * (size_t)N] = acc.z;
-}
-
-// mean = sum / spp ; vec_rgb (common.rs:75-81)
-__global__ __launch_bounds__(256) void k_resolve(DWork wk, DFrame fr, uint8_t* d_rgb8, double* d_color) {
-    const uint32_t lp = blockIdx.x * 256u + threadIdx.x;
-    if (lp >= fr.npx_local) return;
-    const uint32_t N = fr.npx_local;
-    uint32_t x = 0, y = 0;
-    const bool valid = local_pixel(fr, lp, &x, &y);
-    const double n = (double)fr.spp;
-    V3 mean = mk(0., 0., 0.);
-    if (valid) mean = mk(wk.accum[lp] / n, wk.accum[lp + N] / n, wk.accum[lp + 2 * (size_t)N] / n);
-    const uint32_t r = sat_u8(mean.x * 255.0), g = sat_u8(mean.y * 255.0), b = sat_u8(mean.z * 255.0);
-    if (fr.tile_world == 1u) {
-        if (!valid) return;
-        const size_t px = (size_t)y * fr.width + x;
-        if (d_rgb8) { d_rgb8[3 * px] = (uint8_t)r; d_rgb8[3 * px + 1] = (uint8_t)g; d_rgb8[3 * px + 2] = (uint8_t)b; }
-        if (d_color) { d_color[3 * px] = mean.x; d_color[3 * px + 1] = mean.y; d_color[3 * px + 2] = mean.z; }
-    } else if (d_rgb8) {
-        d_rgb8[3 * (size_t)lp] = (uint8_t)r; d_rgb8[3 * (size_t)lp + 1] = (uint8_t)g; d_rgb8[3 * (size_t)lp + 2] = (uint8_t)b;
+    if (FINAL) {
+        resolve_pixel(fr, lp, acc, d_rgb8, d_color);
+    } else {
+        wk.accum[lp] = acc.x; wk.accum[lp + N] = acc.y; wk.accum[lp + 2 * (size_t)N] = acc.z;
     }
 }
 
@@ -1436,11 +1439,9 @@ void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t
     auto k = sc.n_groups > 0 ? (sc.lds_ents ? pick(T{}, T{}) : pick(T{}, F{})) : (sc.lds_ents ? pick(F{}, T{}) : pick(F{}, F{}));
     hipLaunchKernelGGL(k, dim3(bounce_grid()), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
 }
-void launch_accumulate(const DWork& wk, const DFrame& fr, void* stream) {
-    hipLaunchKernelGGL(k_accumulate, dim3(fr.npx_local / 256), dim3(256), 0, (hipStream_t)stream, wk, fr);
-}
-void launch_resolve(const DWork& wk, const DFrame& fr, uint8_t* d_rgb8, double* d_color, void* stream) {
-    hipLaunchKernelGGL(k_resolve, dim3(fr.npx_local / 256), dim3(256), 0, (hipStream_t)stream, wk, fr, d_rgb8, d_color);
+void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream) {
+    hipLaunchKernelGGL(final_batch ? k_accumulate<true> : k_accumulate<false>, dim3(fr.npx_local / 256), dim3(256), 0,
+                       (hipStream_t)stream, wk, fr, d_rgb8, d_color);
 }
 void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream) {
     const uint32_t tiles_x = (w + RRT_TILE_W - 1) / RRT_TILE_W, tiles_y = (h + RRT_TILE_H - 1) / RRT_TILE_H;

@@ -6,10 +6,11 @@ Corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of a
 coalesced streaming read, WRITE_SIZE reads exactly.  The guide calibrates that
 on 16 B/lane accesses and calls other widths uncalibrated; this path moves
-8 B/lane, so it is calibrated here on k_accumulate, whose traffic is known
-exactly (it reads 24 B per path sample and writes 24 B per pixel, nothing
-else): the `calibration` entry holds counter/known ratios (measured: reads
-0.50, writes 1.00, i.e. the guide's factors hold at 8 B/lane).  Reads are
+8 B/lane, so it was calibrated on the round's first collections on k_accumulate,
+whose traffic was then known exactly (it read 24 B per path sample and wrote
+24 B per pixel, nothing else; profiles/r01_v1_pmc_*.csv): counter/known =
+0.50 for reads, 1.00 for writes, i.e. the guide's factors hold at 8 B/lane
+(the `calibration` entry carries these over).  Reads are
 therefore doubled: `hbm_bytes_per_launch` = 2 x FETCH_SIZE + WRITE_SIZE."""
 import csv
 import glob
@@ -36,7 +37,7 @@ def main():
     out = {}
     for k in fetch:
         short = "k_wave_primary" if "k_wave_primary" in k else "k_wave_bounce" if "k_wave_bounce" in k else \
-                "k_accumulate" if "k_accumulate" in k else "k_resolve" if "k_resolve" in k else None
+                "k_accumulate" if "k_accumulate" in k else None
         if not short:
             continue
         fs, n = fetch[k]
@@ -47,14 +48,14 @@ def main():
                       "write_bytes_per_launch": wr, "hbm_bytes_per_launch": 2 * rd + wr,
                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB->bytes, "
                                 "bench.py --steps 2 (tools/collect_pmc.sh); gfx950 correction: reads x2 "
-                                "(calibrated on k_accumulate's known byte counts, see `calibration`)"}
-    if "k_accumulate" in out:
-        # cfg2 bench frame: 1920x1080 pixels padded to 32x8 tiles, 16 spp in one batch
-        npx = ((1920 + 31) // 32) * ((1080 + 7) // 8) * 256
-        a = out["k_accumulate"]
-        out["calibration"] = {"kernel": "k_accumulate", "known_read_bytes": npx * 16 * 24, "known_write_bytes": npx * 24,
-                              "fetch_raw_over_known": a["fetch_bytes_per_launch_raw"] / (npx * 16 * 24),
-                              "write_over_known": a["write_bytes_per_launch"] / (npx * 24)}
+                                "(see `calibration`)"}
+    # Calibration of the x2 read correction at this path's 8 B/lane access width: done on the round's first
+    # collections, when k_accumulate streamed exactly 24 B per path sample in and 24 B per pixel out
+    # (profiles/r01_v1_pmc_{FETCH,WRITE}_SIZE.csv: FETCH_SIZE x 1 KiB = 0.5000 x known reads, WRITE_SIZE x 1 KiB
+    # = 1.000 x known writes).  Since the compact sky samples its traffic is data-dependent, so the ratios are
+    # carried over, not re-measured.
+    out["calibration"] = {"kernel": "k_accumulate (streaming version, profiles/r01_v1_pmc_*.csv)",
+                          "fetch_raw_over_known": 0.5000, "write_over_known": 1.000, "carried_over": True}
     json.dump(out, sys.stdout, indent=1)
     print()
 
