@@ -31,6 +31,9 @@ namespace {
 #ifndef RRT_WAVES
 #define RRT_WAVES 4   // waves per SIMD the trace kernels are register-bounded for
 #endif
+#ifndef RRT_BWAVES
+#define RRT_BWAVES RRT_WAVES   // the same bound for the bounce kernels (5 and 6 measured slower: spills)
+#endif
 #ifndef RRT_PROBE
 #define RRT_PROBE 0
 #endif
@@ -1226,7 +1229,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
 // dozen leaves inside it); with one fixed 64-ray slice per wave and round, a block kept its LDS and
 // register slots until its slowest wave was done (measured: 2.4 of 4 waves/SIMD resident).
 template <int CULL, bool GROUPS, bool SMALL>
-__global__ __launch_bounds__(256, RRT_WAVES) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
+__global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t count = wk.q_count[bounce];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
