@@ -1299,17 +1299,30 @@ __global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr, uint8_t
     const uint32_t pp = (lp & ~255u) | tile_unswz(lp & 255u);   // where the trace kernels put this pixel's samples
     V3 acc = mk(0., 0., 0.);
     if (fr.s0 != 0u) acc = mk(wk.accum[lp], wk.accum[lp + N], wk.accum[lp + 2 * (size_t)N]);
-    for (uint32_t s = 0; s < fr.ns; ++s) {
-        const size_t q = (size_t)s * N + pp;
-        const uint32_t tag = wk.samp32[q];
-        V3 c;
-        if (tag & kSampTexel) {
-            c = mk(by255[tag & 255u], by255[(tag >> 8) & 255u], by255[(tag >> 16) & 255u]);
-        } else {
-            const size_t p = 3 * q;
-            c = mk(wk.samp[p], wk.samp[p + 1], wk.samp[p + 2]);
+    // four samples per trip: their tags, then the colours the tags point to, are requested together
+    // (the kernel is a latency chain tag -> colour per sample otherwise); the sum stays in sample order
+    for (uint32_t s0 = 0; s0 < fr.ns; s0 += 4u) {
+        uint32_t tag[4];
+        V3 c[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t s = s0 + j < fr.ns ? s0 + j : fr.ns - 1u;     // clamped: re-reads the last sample, not added
+            tag[j] = wk.samp32[(size_t)s * N + pp];
         }
-        acc = (fr.s0 + s == 0u) ? c : acc + c;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t s = s0 + j < fr.ns ? s0 + j : fr.ns - 1u;
+            const size_t p = 3 * ((size_t)s * N + pp);
+            c[j] = mk(0., 0., 0.);
+            if (!(tag[j] & kSampTexel)) c[j] = mk(wk.samp[p], wk.samp[p + 1], wk.samp[p + 2]);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            if (s0 + j >= fr.ns) break;
+            const uint32_t t = tag[j];
+            const V3 v = (t & kSampTexel) ? mk(by255[t & 255u], by255[(t >> 8) & 255u], by255[(t >> 16) & 255u]) : c[j];
+            acc = (fr.s0 + s0 + j == 0u) ? v : acc + v;
+        }
     }
     if (FINAL) {
         resolve_pixel(fr, lp, acc, d_rgb8, d_color);
