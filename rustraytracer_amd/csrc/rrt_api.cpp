@@ -347,7 +347,9 @@ int commit(rrt_scene* s) {
             break;
         }
     for (int f = 0; f < 6; ++f) {
-        HIP_TRY(s->sky[f].d.upload(s->sky[f].rgb.data(), s->sky[f].rgb.size()));
+        // + 4 readable bytes: the kernels fetch a texel as one unaligned dword (its 3 bytes and the next one)
+        HIP_TRY(s->sky[f].d.ensure(s->sky[f].rgb.size() + 4));
+        HIP_TRY(hipMemcpy(s->sky[f].d.p, s->sky[f].rgb.data(), s->sky[f].rgb.size(), hipMemcpyHostToDevice));
         d.sky[f] = s->sky[f].d.as<uint8_t>();
         d.sky_w[f] = s->sky[f].w;
         d.sky_h[f] = s->sky[f].h;

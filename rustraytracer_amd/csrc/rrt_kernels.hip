@@ -791,8 +791,10 @@ RRT_DEV uint32_t sky_texel(const DScene& sc, LDS lds, V3 dir) {
     uint32_t px = sat_u32(u * (double)w), py = sat_u32(v * (double)hgt);
     if (px >= w) px = w - 1;
     if (py >= hgt) py = hgt - 1;
+    // one unaligned dword instead of three byte loads (the face buffers carry 4 spare bytes at the end)
+    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
     const RRT_GLOBAL uint8_t* p = as_global(face) + ((size_t)py * w + px) * 3;
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+    return *(const RRT_GLOBAL u32_unaligned*)p & 0x00ffffffu;
 }
 // CubemapBehavior::compute's rgb / 255.0 (cubemap.rs:70-74) through the 256-entry quotient table
 template <class LDS>
