@@ -473,12 +473,14 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
         CNT(7);
         // the six ropes travel with the box (one round trip); the face picks among registers
         typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+        typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+        static_assert(sizeof(DLeaf) % 16 == 0 && offsetof(DLeaf, rope) % 16 == 0, "ropes are fetched as 16 + 8 bytes");
         const V3 mn = ld3g(L->mn), mx = ld3g(L->mx);
-        const i32x2 r01 = *(const RRT_GLOBAL i32x2*)&L->rope[0], r23 = *(const RRT_GLOBAL i32x2*)&L->rope[2],
-                    r45 = *(const RRT_GLOBAL i32x2*)&L->rope[4];
+        const i32x4 r03 = *(const RRT_GLOBAL i32x4*)&L->rope[0];
+        const i32x2 r45 = *(const RRT_GLOBAL i32x2*)&L->rope[4];
         point = box_exit(mn, mx, point, d, inv) + d * 0.001;
         const int pl = get_plane(point, mn, mx);
-        const int32_t nb = pl == 0 ? r01.x : pl == 1 ? r01.y : pl == 2 ? r23.x : pl == 3 ? r23.y : pl == 4 ? r45.x : r45.y;
+        const int32_t nb = pl == 0 ? r03.x : pl == 1 ? r03.y : pl == 2 ? r03.z : pl == 3 ? r03.w : pl == 4 ? r45.x : r45.y;
         if (nb < 0) return;
         lr = find_point(M.nodes, M.boxes, lnodes, nb, point);
     }
