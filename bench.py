@@ -111,6 +111,7 @@ def main():
                     help="BASELINE.json config to run (default cfg2 = the contract's workload; the others "
                          "print the same line without roofline/cpu_baseline)")
     ap.add_argument("--budget-gib", type=float, default=0.0, help="work-buffer budget in GiB (0 = library default)")
+    ap.add_argument("--cull-mode", type=int, default=-1, help="rrt_set_cull_mode (0 off, 1 on, 2 verify; -1 = library default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -138,6 +139,8 @@ def main():
     scene = getattr(scenes, scene_fn)(Hst.World(device=local_rank), Hst.loaders)
     if args.budget_gib > 0:
         scene.set_work_budget(int(args.budget_gib * (1 << 30)))
+    if args.cull_mode >= 0:
+        scene.set_cull_mode(args.cull_mode)
     scene.commit()                                   # scene resident in HBM before timing
     spp = SPP * world if args.scaling == "weak" else SPP
     st = Hst.make_settings(W, H, spp=spp, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune,
