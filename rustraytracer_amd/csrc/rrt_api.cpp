@@ -340,8 +340,11 @@ int commit(rrt_scene* s) {
     d.lds_mats = d.lds_ents ? (int32_t)s->mats.size() : 0;
     d.lds_mesh = -1;
     d.lds_nodes = 0;
+    // RRT_MAX_LDS_NODES (tests): lower the staging limit, so small meshes take the large-mesh code paths
+    int32_t max_lds_nodes = rrt::kMaxLdsNodes;
+    if (const char* e = getenv("RRT_MAX_LDS_NODES")) max_lds_nodes = std::min<int32_t>(max_lds_nodes, std::max(0, atoi(e)));
     for (size_t i = 0; i < s->meshes.size(); ++i)
-        if (s->meshes[i]->tree.n_nodes() <= rrt::kMaxLdsNodes) {
+        if (s->meshes[i]->tree.n_nodes() <= max_lds_nodes) {
             d.lds_mesh = (int32_t)i;
             d.lds_nodes = s->meshes[i]->tree.n_nodes();
             break;

@@ -465,6 +465,29 @@ def test_large_entity_count_takes_the_global_memory_kernels(H, O, scenes):
         assert len(np.unique(go["ids"][..., 0])) > 50
 
 
+def test_large_mesh_paths_on_small_meshes(H, O, scenes, monkeypatch):
+    """RRT_MAX_LDS_NODES=0 makes every mesh take the code paths of meshes too large for the LDS descent array
+    (descent array read from global memory inside the wavefront kernels instead of LDS).  Same results, bit
+    for bit: main.rs scene with jitter, the diffuse-bounce UFO, incoherent rays, cull modes 1 and 2."""
+    monkeypatch.setenv("RRT_MAX_LDS_NODES", "0")
+    g, c = scenes.main_rs_scene(H.World(device=0), H.loaders), scenes.main_rs_scene(O.OracleScene(), O)
+    for mode in (1, 2):
+        g.set_cull_mode(mode)
+        go, co = g.render(960, 540, spp=3, seed=2), c.render(960, 540, spp=3, seed=2)
+        _same(go, co)
+        assert go["stats"]["cull_violations"] == 0 and go["stats"]["traversal_overflow"] == 0
+    rays = _random_rays(np.random.default_rng(5), 200000)
+    gt, ct = g.trace_rays(rays), c.trace_rays(rays)
+    for k in ("ent", "tri", "t", "pos", "normal"):
+        assert np.array_equal(gt[k], ct[k]), k
+    g, c = scenes.cfg4_scene(H.World(device=0), H.loaders), scenes.cfg4_scene(O.OracleScene(), O)
+    go, co = g.render(640, 360, spp=4, seed=9), c.render(640, 360, spp=4, seed=9)
+    _same(go, co)
+    g, c = scenes.many_entity_scene(H.World(device=0), H.loaders), scenes.many_entity_scene(O.OracleScene(), O)
+    go, co = g.render(480, 270, max_bounce=4), c.render(480, 270, max_bounce=4)
+    _same(go, co)
+
+
 def test_cpp_host_main_rs_writes_bruh_png(golden_dir, tmp_path):
     """examples/main.cpp = src/main.rs restated on the C++ host mirror (include/rrt_host.hpp);
     the PNG it writes through the C ABI must decode to the reference's bruh.png."""
