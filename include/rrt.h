@@ -85,7 +85,7 @@ typedef struct rrt_stats {
     uint64_t traversal_overflow; /* rays that exceeded the leaf-visit safety bound (expected 0)       */
     double gpu_ms;             /* hipEvent span of the last render's kernels                          */
     double primary_kernel_ms;  /* summed hipEvent duration of the primary-ray kernel launches         */
-    double bounce_kernel_ms;   /* summed hipEvent duration of the bounce-queue kernel launches        */
+    double bounce_kernel_ms;   /* hipEvent span of the bounce-queue kernel launches (one pair per batch around its levels) */
     uint32_t primary_kernel_launches;
     uint32_t bounce_kernel_launches;
     uint32_t n_batches;
