@@ -72,6 +72,16 @@ def cpu_leg(n_threads, row_stride=1):
         dt += time.perf_counter() - t0
         frames += 1
         c = dict(zip(O.COUNTER_NAMES, (int(x) for x in out["counters"])))
+    # the reference's own work split (SURVEY 8d "faithful" mode): 12 threads over 12 contiguous row-major
+    # chunks of W*H/12 pixels (tracer.rs:117-158) -- the slowest chunk sets the time
+    O.lib().orc_set_static_chunks(1)
+    t0 = time.perf_counter()
+    outf = cpu.render(W, H, spp=SPP, seed=0, n_threads=12, want=())
+    dtf = time.perf_counter() - t0
+    O.lib().orc_set_static_chunks(0)
+    faithful = {"value": int(outf["counters"][0]) / dtf / 1e6, "unit": "Mrays/s", "threads": 12,
+                "sample": "one full %dx%d frame at %d spp in 12 static contiguous pixel chunks as tracer.rs:117-158: "
+                          "%d rays in %.2f s" % (W, H, SPP, int(outf["counters"][0]), dtf)}
     rows = len(range(3, H, row_stride))
     # per-primary-ray traversal work: closest-hit of the sample-0 primary rays of those rows
     import ctypes as C
@@ -94,6 +104,7 @@ def cpu_leg(n_threads, row_stride=1):
                   "C++ f64 restatement of the reference, rows handed to threads dynamically (no per-hit Material "
                   "clone: optimistic for the Rust binary)" % (H - 1, row_stride, W, H, rows, SPP, frames,
                                                               c["rays"] * frames, dt),
+        "reference_work_split": faithful,
     }, c, pc, k
 
 

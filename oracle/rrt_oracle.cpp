@@ -878,6 +878,9 @@ void orc_cast_rays(void* h, const double* rays, int64_t n, uint32_t max_bounce, 
     }
 }
 
+static bool g_static_chunks = false;
+void orc_set_static_chunks(int on) { g_static_chunks = on != 0; }
+
 // ---- render (tracer.rs:77-175, minus PNG save).  Rows y0 <= y < y1 with
 // (y - y0) % row_stride == 0 are rendered (the CPU-baseline leg times a bounded
 // strided sample; tests render everything).  Threads take rows from a shared
@@ -895,13 +898,27 @@ int orc_render(void* h, const Camera* cam, const Settings* stp, int64_t y0, int6
     std::vector<Counters> cs(nt);
     std::vector<std::thread> th;
     std::atomic<int64_t> next_row{y0};
+    // g_static_chunks: the reference's own work split (tracer.rs:117-158): thread ti renders the contiguous
+    // row-major pixel range [ti * chunk, (ti + 1) * chunk), chunk = W*H / n_threads, the last one the rest.
+    const bool static_chunks = g_static_chunks;
+    const int64_t npx = (int64_t)st.width * st.height, chunk = npx / nt;
     for (uint32_t ti = 0; ti < nt; ++ti) {
         th.emplace_back([&, ti]() {
             Counters& c = cs[ti];
+            int64_t row = 0;
             for (;;) {
-                const int64_t y = next_row.fetch_add(row_stride);
-                if (y >= y1) break;
-                for (uint32_t x = 0; x < st.width; ++x) {
+                int64_t y, xa = 0, xb = st.width;
+                if (static_chunks) {
+                    const int64_t p0 = ti * chunk, p1 = ti + 1 == nt ? npx : (ti + 1) * chunk;
+                    y = p0 / st.width + row++;
+                    if (y * (int64_t)st.width >= p1) break;
+                    xa = std::max<int64_t>(p0 - y * st.width, 0);
+                    xb = std::min<int64_t>(p1 - y * st.width, st.width);
+                } else {
+                    y = next_row.fetch_add(row_stride);
+                    if (y >= y1) break;
+                }
+                for (uint32_t x = (uint32_t)xa; x < (uint32_t)xb; ++x) {
                     const int64_t i = y * st.width + x;
                     V3 sum{0, 0, 0};
                     for (uint32_t sp = 0; sp < st.spp; ++sp) {
