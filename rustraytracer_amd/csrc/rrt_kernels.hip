@@ -900,6 +900,7 @@ RRT_DEV void continuation(const DFrame& fr, const DMaterial& m, V3 pos, V3 n, V3
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <class T, class B>
 RRT_DEV T& at_off(B* base, uint32_t byte_off) { return *(T*)((char*)base + byte_off); }
+constexpr uint32_t kDeadSky = 0x80000000u;     // queue entry, path word: the cast that spawned this ray has mix() == +-0.0
 constexpr uint32_t kSampTexel = 0x01000000u;   // samp32 tag: the low 24 bits are a sky texel (else: the colour is in samp)
 // level record {A.xyz, Pm.xyz, mixR}
 RRT_DEV void st_rec(double* level_base, uint32_t off, V3 A, V3 Pm, double mixR) {
@@ -1004,11 +1005,11 @@ RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y
 template <bool PRIMARY, int CULL, bool GROUPS, class LDS>
 RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFrame& fr, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
-                         uint32_t pixel, uint32_t sample) {
+                         uint32_t pixel, uint32_t sample, bool dead_sky = false) {
     const uint64_t P = wk.cap;
     const uint32_t rec_off = path * (uint32_t)(kRecDoubles * 8);
     const bool aov = sample == 0u;
-    bool cont = false, compact = false;
+    bool cont = false, compact = false, zero_mix = false;
     V3 ro = mk(0., 0., 0.), rd = mk(0., 0., 0.);
     if (active) {
         Closest c;
@@ -1030,6 +1031,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             shade_direct(sc, lds, m, d, h.normal, &A, &Pm);
             cont = !(bounce > fr.max_bounce) && !(fr.prune && m.mixR == 0.0);
             if (cont) {
+                zero_mix = m.mixR == 0.0;
                 st_rec(wk.rec + (size_t)bounce * kRecDoubles * P, rec_off, A, Pm, m.mixR);
                 uint32_t kp = pixel, ks = sample;
                 if (!PRIMARY && m.lobe == 2) {
@@ -1061,7 +1063,10 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             double mr;
             V3 A, Pm;
             ld_rec(wk.rec + (size_t)k * kRecDoubles * P, rec_off, &A, &Pm, &mr);
-            col = sky_color(sc, lds, d);
+            // dead_sky: the enclosing cast's mix() is +-0.0 (the queue entry says so), and a sky colour is
+            // texel/255 >= +0, finite: its product with the mix is the same signed zero whatever the texel, so
+            // the texel is not fetched.  The ray itself was cast like any other (reference ray semantics).
+            col = dead_sky ? mk(0., 0., 0.) : sky_color(sc, lds, d);
             col = (A + col * mr) + Pm;
             fold_from = k;
         }
@@ -1089,7 +1094,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
         at_off<f64x2>(q, off) = f64x2{ro.x, ro.y};
         at_off<f64x2>(q, off + 16u) = f64x2{ro.z, rd.x};
         at_off<f64x2>(q, off + 32u) = f64x2{rd.y, rd.z};
-        at_off<uint2>(q, off + 48u) = make_uint2(path, (uint32_t)medium);
+        at_off<uint2>(q, off + 48u) = make_uint2(path | (zero_mix ? kDeadSky : 0u), (uint32_t)medium);
     }
 }
 
@@ -1259,6 +1264,7 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
         const bool active = i < count;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         uint32_t path = 0;
+        bool dead_sky = false;
         int32_t medium = -1;
         if (active) {
             const uint32_t off = i * (uint32_t)(kRecDoubles * 8);
@@ -1266,10 +1272,11 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
             const uint2 pm = at_off<uint2>(q, off + 48u);
             o = mk(a.x, a.y, b.x);
             d = mk(b.y, c.x, c.y);
-            path = pm.x;
+            path = pm.x & ~kDeadSky;
+            dead_sky = (pm.x & kDeadSky) != 0u;
             medium = (int32_t)pm.y;
         }
-        process_ray<false, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u);
+        process_ray<false, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, dead_sky);
     }
 }
 
