@@ -1032,6 +1032,14 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             cont = !(bounce > fr.max_bounce) && !(fr.prune && m.mixR == 0.0);
             if (cont) {
                 zero_mix = m.mixR == 0.0;
+                if (PRIMARY && zero_mix) {
+                    // What this path's sample will be if the (dead) reflection ray ends in the sky, computed with the
+                    // child's own expression on col = +0: the level-1 kernel then has nothing to read or write for
+                    // it.  If the ray hits something instead, that kernel overwrites the sample.
+                    const V3 c0 = (A + mk(0., 0., 0.) * m.mixR) + Pm;
+                    at_off<f64x2>(wk.samp, path * 24u) = f64x2{c0.x, c0.y};
+                    at_off<double>(wk.samp, path * 24u + 16u) = c0.z;
+                }
                 st_rec(wk.rec + (size_t)bounce * kRecDoubles * P, rec_off, A, Pm, m.mixR);
                 uint32_t kp = pixel, ks = sample;
                 if (!PRIMARY && m.lobe == 2) {
@@ -1062,6 +1070,9 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             const uint32_t k = bounce - 1u;
             double mr;
             V3 A, Pm;
+            if (dead_sky && bounce == 1u) {
+                compact = true;          // the primary kernel already left this outcome in samp (see there)
+            } else {
             ld_rec(wk.rec + (size_t)k * kRecDoubles * P, rec_off, &A, &Pm, &mr);
             // dead_sky: the enclosing cast's mix() is +-0.0 (the queue entry says so), and a sky colour is
             // texel/255 >= +0, finite: its product with the mix is the same signed zero whatever the texel, so
@@ -1069,6 +1080,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             col = dead_sky ? mk(0., 0., 0.) : sky_color(sc, lds, d);
             col = (A + col * mr) + Pm;
             fold_from = k;
+            }
         }
         if (PRIMARY && !compact) at_off<uint32_t>(wk.samp32, path * 4u) = 0u;   // "see samp" (written now or by a bounce level)
         if (!cont && !compact) {
