@@ -242,19 +242,21 @@ def main():
             # DESIGN.md "Measurement" states: the scene of this config (~0.4 MB of nodes/triangles) is
             # cache-resident, so the bytes that MUST cross HBM per primary ray are its outputs only:
             #   path that ends in the sky: 3 B cubemap texel read + 4 B compact sample (the texel itself, samp32)
-            #   continuing path: 56 B shading record + 56 B queue entry (o, d, path, medium) + 4 B samp32 tag
+            #   continuing path: 56 B shading record + 56 B queue entry (o, d, path, medium) + 4 B samp32 tag,
+            #                    + 24 B sample colour left in advance when its reflection ray has mix 0.0
             # `achieved` = those bytes x rays per launch / measured launch time (hipEvents on the launch stream).
             # The kernel is f64-VALU/latency bound; that ceiling is reported beside it as valu_f64.
             launch_ms = prim_ms / max(prim_n, 1)
             rays_per_launch = stats["primary_rays"] / max(prim_n, 1)
             lv = stats["level_rays"]
             cont = lv[1] / max(lv[0], 1)
-            hbm_bytes_ray = (1.0 - cont) * 7.0 + cont * 116.0
+            dead = stats["zero_mix_paths"] / max(lv[0], 1)
+            hbm_bytes_ray = (1.0 - cont) * 7.0 + cont * 116.0 + dead * 24.0
             ach = hbm_bytes_ray * rays_per_launch / (launch_ms * 1e-3) / 1e9
             roof = {"kernel": "k_wave_primary", "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
                     "achieved": ach, "frac": ach / PEAK_HBM_GBS, "traffic": None,
                     "avg_launch_ms": launch_ms, "launches_per_step": prim_n, "rays_per_launch": rays_per_launch,
-                    "hbm_bytes_per_ray": hbm_bytes_ray, "continuing_fraction": cont,
+                    "hbm_bytes_per_ray": hbm_bytes_ray, "continuing_fraction": cont, "zero_mix_fraction": dead,
                     "other_kernels": {"k_wave_bounce_ms_per_step": bnc_ms, "k_wave_bounce_launches": bnc_n,
                                       "k_wave_primary_ms_per_step": prim_ms, "gpu_ms_per_step": stats["gpu_ms"],
                                       "level_rays": lv}}

@@ -53,6 +53,7 @@ pub struct rrt_stats {
     pub reserved: u32,
     pub level_rays: [u64; 4],
     pub cull_violations: u64,
+    pub zero_mix_paths: u64,
 }
 
 pub const RRT_TILE_W: u32 = 32;

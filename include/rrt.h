@@ -92,6 +92,7 @@ typedef struct rrt_stats {
     uint32_t reserved;
     uint64_t level_rays[4];    /* rays cast at bounce level 0,1,2,3 (level 0 = primary)               */
     uint64_t cull_violations;  /* cull mode 2 only: entries the cull skipped but the exact test accepts (must be 0) */
+    uint64_t zero_mix_paths;   /* primary hits whose reflection ray was cast with mix() == 0.0           */
 } rrt_stats;
 
 #define RRT_TILE_W 32

@@ -32,7 +32,8 @@ class Stats(C.Structure):
                 ("primary_kernel_ms", C.c_double), ("bounce_kernel_ms", C.c_double),
                 ("primary_kernel_launches", C.c_uint32), ("bounce_kernel_launches", C.c_uint32),
                 ("n_batches", C.c_uint32), ("reserved", C.c_uint32),
-                ("level_rays", C.c_uint64 * 4), ("cull_violations", C.c_uint64)]
+                ("level_rays", C.c_uint64 * 4), ("cull_violations", C.c_uint64),
+                ("zero_mix_paths", C.c_uint64)]
 
 
 # every symbol include/rrt.h and include/rrt_host.h declare

@@ -847,6 +847,7 @@ int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) try {
     s->stats.rays_traced = s->stats.primary_rays + dev[0];
     s->stats.traversal_overflow = dev[1];
     s->stats.cull_violations = dev[2];
+    s->stats.zero_mix_paths = dev[3];
     s->stats.level_rays[0] = s->stats.primary_rays;
     for (int l = 1; l < 4; ++l) s->stats.level_rays[l] = dev[4 + l];
     *out = s->stats;

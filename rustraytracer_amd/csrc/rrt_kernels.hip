@@ -1098,6 +1098,10 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             }
         }
     }
+    if (PRIMARY) {   // stats[3]: primary hits that continue with a dead (mix 0.0) ray -- one atomic per wave that has any
+        const unsigned long long zm = __ballot(cont && zero_mix);
+        if (zm != 0ull && (int)__lane_id() == __ffsll((long long)zm) - 1) atomicAdd(&wk.stats[3], (unsigned long long)__popcll(zm));
+    }
     const uint32_t slot = queue_slot(&wk.q_count[bounce + 1], cont);
     if (cont) {
         // queue entry {o.xyz, d.xyz, (path, medium)}
