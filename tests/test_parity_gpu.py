@@ -488,6 +488,32 @@ def test_large_mesh_paths_on_small_meshes(H, O, scenes, monkeypatch):
     _same(go, co)
 
 
+def test_dead_reflection_rays_are_value_identical(H, O, scenes):
+    """Reflection rays cast with mix() == +0.0 / -0.0: the kernels still cast them (same ray count
+    as the oracle) but do not fetch the sky texel behind them and settle their sky outcome at the parent.  The
+    f64 colours must equal the oracle's BIT FOR BIT (signed zeros included), also where such a ray hits
+    something (a mirror and a lit sphere stand in its way), at depth (max_bounce 4) and with black materials
+    whose A and Pm terms are zeros themselves."""
+    def build(b, L):
+        scenes.empty_world(b, L, "sky")
+        dead_p = b.add_material(scenes.color_vec(200, 80, 40), 1.0, 1.0, 0.0, 0.3, 20)
+        dead_n = b.add_material(scenes.color_vec(0, 0, 0), 1.0, 0.0, -0.0, 0.0, 20)
+        mirror = b.add_material(scenes.color_vec(0, 0, 0), 0.8, 0.0, 1.0, 0.1, 20)
+        lit = b.add_material(scenes.color_vec(60, 160, 90), 0.9, 0.8, 0.2, 0.2, 20)
+        b.add_sphere((-2.5, 0.0, 9.0), 1.5, dead_p)
+        b.add_sphere((2.5, 0.0, 9.0), 1.5, dead_n)
+        b.add_sphere((0.0, 2.2, 7.0), 1.0, mirror)
+        b.add_sphere((0.0, -2.2, 7.0), 1.0, lit)
+        return b
+    g, c = build(H.World(device=0), H.loaders), build(O.OracleScene(), O)
+    for mb in (2, 4):
+        go, co = g.render(640, 360, spp=2, seed=4, max_bounce=mb), c.render(640, 360, spp=2, seed=4, max_bounce=mb)
+        _same(go, co)
+        assert np.array_equal(go["color"].view(np.uint64), co["color"].view(np.uint64))
+        assert go["stats"]["rays_traced"] == int(co["counters"][0])
+        assert go["stats"]["zero_mix_paths"] > 10000
+
+
 def test_cpp_host_main_rs_writes_bruh_png(golden_dir, tmp_path):
     """examples/main.cpp = src/main.rs restated on the C++ host mirror (include/rrt_host.hpp);
     the PNG it writes through the C ABI must decode to the reference's bruh.png."""
