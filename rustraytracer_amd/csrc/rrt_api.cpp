@@ -430,7 +430,7 @@ int ensure_work(rrt_scene* s, const FramePlan& pl, rrt::DWork* wk) {
         HIP_TRY(s->w_q[i].ensure(P * rrt::kRecDoubles * 8));
         wk->q[i] = s->w_q[i].as<double>();
     }
-    HIP_TRY(s->w_qcount.ensure((rrt::kMaxLevels + 1) * 4));
+    HIP_TRY(s->w_qcount.ensure(2 * (rrt::kMaxLevels + 1) * 4));
     HIP_TRY(s->w_rec.ensure(P * rrt::kRecDoubles * 8 * pl.levels));
     HIP_TRY(s->w_samp.ensure(P * 3 * 8));
     HIP_TRY(s->w_samp32.ensure(P * 4));
@@ -482,7 +482,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     for (uint32_t b = 0; b < pl.n_batches; ++b) {
         fr.s0 = b * pl.batch_spp;
         fr.ns = std::min(pl.batch_spp, st->spp - fr.s0);
-        HIP_TRY(hipMemsetAsync(wk.q_count, 0, (rrt::kMaxLevels + 1) * 4, stream));
+        HIP_TRY(hipMemsetAsync(wk.q_count, 0, 2 * (rrt::kMaxLevels + 1) * 4, stream));
         TimedLaunch* tl;
         rc = timed_slot(s, &tl);
         if (rc) return rc;

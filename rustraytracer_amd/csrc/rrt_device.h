@@ -147,7 +147,7 @@ constexpr int32_t kMaxLdsNodes = 3072;   // 48 KB of LDS per 256-thread block at
 constexpr int kRecDoubles = 7;
 struct DWork {
     double* q[2];        // [P][7]          ray queues (read / written alternately by the bounce levels)
-    uint32_t* q_count;   // [kMaxLevels + 1] entries used per bounce level
+    uint32_t* q_count;   // [2][kMaxLevels + 1] queue entries per bounce level: live rays (from the front), dead rays (from the back)
     double* rec;         // [levels][P][7]  shading records of the continuing casts
     double* samp;        // [P][3]          finished per-sample colour ...
     uint32_t* samp32;    // [P]             ... unless this says kSampTexel | sky texel (a primary ray that ended in the sky)

@@ -45,6 +45,9 @@ namespace {
 #endif
 #if RRT_PROBE
 __device__ unsigned long long g_phase[32];
+#if RRT_PROBE == 2      // timing only: the event counters' atomics would be what is timed
+#define CNT(i) do { } while (0)
+#else
 #define CNT(i)                                                                          \
     do {                                                                                \
         const unsigned long long m_ = __ballot(1);                                      \
@@ -53,8 +56,18 @@ __device__ unsigned long long g_phase[32];
             atomicAdd(&g_phase[2 * (i) + 1], (unsigned long long)__popcll(m_));         \
         }                                                                               \
     } while (0)
+#endif
+// TSTAMP: cycle counter after everything outstanding has landed; TADD(i, dt): g_phase[24 + i] += dt by the wave's first lane
+#define TSTAMP() (__builtin_amdgcn_s_waitcnt(0), (unsigned long long)__builtin_readcyclecounter())
+#define TADD(i, dt)                                                                     \
+    do {                                                                                \
+        const unsigned long long m_ = __ballot(1);                                      \
+        if ((int)__lane_id() == __ffsll((long long)m_) - 1) atomicAdd(&g_phase[24 + (i)], (unsigned long long)(dt)); \
+    } while (0)
 #else
 #define CNT(i) do { } while (0)
+#define TSTAMP() 0ull
+#define TADD(i, dt) do { } while (0)
 #endif
 
 struct V3 {
@@ -1102,10 +1115,16 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
         const unsigned long long zm = __ballot(cont && zero_mix);
         if (zm != 0ull && (int)__lane_id() == __ffsll((long long)zm) - 1) atomicAdd(&wk.stats[3], (unsigned long long)__popcll(zm));
     }
-    const uint32_t slot = queue_slot(&wk.q_count[bounce + 1], cont);
+    // Live rays fill the next queue from its front, dead (mix 0.0) rays from its back: a 64-ray unit of the
+    // next level is then all live or all dead.  In one mixed queue the units were mixed too (waves of UFO
+    // tiles and of sphere tiles append at the same time), and a unit costs what its dearest lane costs:
+    // measured 10.7 k cycles for an all-dead unit against 43 k for one with live rays in it.
+    const uint32_t slot_live = queue_slot(&wk.q_count[bounce + 1], cont && !zero_mix);
+    const uint32_t slot_dead = queue_slot(&wk.q_count[kMaxLevels + 1 + bounce + 1], cont && zero_mix);
     if (cont) {
         // queue entry {o.xyz, d.xyz, (path, medium)}
         double* q = wk.q[(bounce + 1) & 1];
+        const uint32_t slot = zero_mix ? (uint32_t)P - 1u - slot_dead : slot_live;
         const uint32_t off = slot * (uint32_t)(kRecDoubles * 8);
         at_off<f64x2>(q, off) = f64x2{ro.x, ro.y};
         at_off<f64x2>(q, off + 16u) = f64x2{ro.z, rd.x};
@@ -1256,12 +1275,12 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
 template <int CULL, bool GROUPS, bool SMALL>
 __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t count = wk.q_count[bounce];
+    const uint32_t n_live = wk.q_count[bounce], n_dead = wk.q_count[kMaxLevels + 1 + bounce], count = n_live + n_dead;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         atomicAdd(&wk.stats[0], (unsigned long long)count);
         if (bounce < 4u) atomicAdd(&wk.stats[4 + bounce], (unsigned long long)count);
     }
-    const uint32_t n_units = (count + 63u) >> 6;
+    const uint32_t live_units = (n_live + 63u) >> 6, n_units = live_units + ((n_dead + 63u) >> 6);
     if (blockIdx.x >= n_units) return;          // whole block idle (block-uniform): skip the staging too
     const uint32_t my_units = (n_units - blockIdx.x + gridDim.x - 1u) / gridDim.x;
     RRT_LDS uint32_t* next_unit = (RRT_LDS uint32_t*)(smem + lds_layout_bytes(sc));
@@ -1271,13 +1290,22 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     const uint64_t P = wk.cap;
     double* q = wk.q[bounce & 1];
     const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long tk0 = TSTAMP();
+    unsigned long long acc_q = 0, acc_p = 0, acc_n = 0, acc_dp = 0, acc_dn = 0;
+    (void)tk0; (void)acc_q; (void)acc_p; (void)acc_n; (void)acc_dp; (void)acc_dn;
     for (;;) {
+        const unsigned long long t0 = TSTAMP();
+        (void)t0;
         uint32_t u = 0u;
         if (lane == 0u) u = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
         if (u >= my_units) break;               // wave-uniform; the counter only grows, so every wave gets here
-        const uint32_t i = (u * gridDim.x + blockIdx.x) * 64u + lane;
-        const bool active = i < count;
+        // unit -> queue entries: live units count up from entry 0, dead units down from entry P - 1
+        const uint32_t unit = u * gridDim.x + blockIdx.x;
+        const bool live_unit = unit < live_units;
+        const uint32_t k = (live_unit ? unit : unit - live_units) * 64u + lane;
+        const bool active = k < (live_unit ? n_live : n_dead);
+        const uint32_t i = live_unit ? k : (uint32_t)P - 1u - k;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         uint32_t path = 0;
         bool dead_sky = false;
@@ -1292,8 +1320,13 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
             dead_sky = (pm.x & kDeadSky) != 0u;
             medium = (int32_t)pm.y;
         }
+        const unsigned long long t1 = TSTAMP();
         process_ray<false, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, dead_sky);
+        const unsigned long long t2 = TSTAMP();
+        acc_q += t1 - t0; acc_p += t2 - t1; acc_n += 1;
+        if (__ballot(active && !dead_sky) == 0ull) { acc_dp += t2 - t1; acc_dn += 1; }
     }
+    if (bounce == 1u) { TADD(0, acc_q); TADD(1, acc_p); TADD(2, acc_n); TADD(3, TSTAMP() - tk0); TADD(4, 1); TADD(5, acc_dp); TADD(6, acc_dn); }
 }
 
 // mean = sum / spp ; vec_rgb (common.rs:75-81); row-major frame or this rank's compact tile buffer

@@ -27,3 +27,10 @@ wr = max(out[0], 1)
 for i, n in enumerate(NAMES):
     wv, ln = out[2 * i], out[2 * i + 1]
     print("%-24s %14d %14d %10.1f %12.2f %12.2f" % (n, wv, ln, ln / max(wv, 1), wv / wr, ln / max(out[1], 1)))
+
+t = [out[24 + i] for i in range(8)]
+if t[2]:
+    print("bounce level 1, per 64-ray unit: grab + queue read %.0f cycles, process_ray %.0f cycles (%d units); per wave: %.0f cycles in the unit loop (%d waves)"
+          % (t[0] / t[2], t[1] / t[2], t[2], t[3] / max(t[4], 1), t[4]))
+    print("   units whose rays are all dead (mix 0.0 parents): %d, process_ray %.0f cycles each; the others: %d, %.0f cycles each"
+          % (t[6], t[5] / max(t[6], 1), t[2] - t[6], (t[1] - t[5]) / max(t[2] - t[6], 1)))
