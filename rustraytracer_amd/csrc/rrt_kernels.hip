@@ -1018,7 +1018,7 @@ RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y
 template <bool PRIMARY, int CULL, bool GROUPS, class LDS>
 RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFrame& fr, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
-                         uint32_t pixel, uint32_t sample, bool dead_sky = false) {
+                         uint32_t pixel, uint32_t sample, bool dead_sky = false, unsigned long long* tacc = nullptr) {
     const uint64_t P = wk.cap;
     const uint32_t rec_off = path * (uint32_t)(kRecDoubles * 8);
     const bool aov = sample == 0u;
@@ -1027,7 +1027,10 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
     if (active) {
         Closest c;
         CNT(0);
+        const unsigned long long tc0 = TSTAMP();
         closest_hit<CULL, GROUPS>(sc, lds, o, d, medium, &c, wk.stats);
+        if (RRT_PROBE == 2 && tacc) *tacc += TSTAMP() - tc0;
+        (void)tc0;
         Hit h;
         finish_hit(sc, lds, o, d, c, &h);
         const int32_t ent = c.ent;
@@ -1291,8 +1294,8 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     double* q = wk.q[bounce & 1];
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long tk0 = TSTAMP();
-    unsigned long long acc_q = 0, acc_p = 0, acc_n = 0, acc_dp = 0, acc_dn = 0;
-    (void)tk0; (void)acc_q; (void)acc_p; (void)acc_n; (void)acc_dp; (void)acc_dn;
+    unsigned long long acc_q = 0, acc_p = 0, acc_n = 0, acc_dp = 0, acc_dn = 0, acc_lc = 0;
+    (void)tk0; (void)acc_q; (void)acc_p; (void)acc_n; (void)acc_dp; (void)acc_dn; (void)acc_lc;
     for (;;) {
         const unsigned long long t0 = TSTAMP();
         (void)t0;
@@ -1321,12 +1324,14 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
             medium = (int32_t)pm.y;
         }
         const unsigned long long t1 = TSTAMP();
-        process_ray<false, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, dead_sky);
+        unsigned long long tch = 0;
+        process_ray<false, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, dead_sky, &tch);
         const unsigned long long t2 = TSTAMP();
+        if (__ballot(active && !dead_sky) != 0ull) acc_lc += tch;
         acc_q += t1 - t0; acc_p += t2 - t1; acc_n += 1;
         if (__ballot(active && !dead_sky) == 0ull) { acc_dp += t2 - t1; acc_dn += 1; }
     }
-    if (bounce == 1u) { TADD(0, acc_q); TADD(1, acc_p); TADD(2, acc_n); TADD(3, TSTAMP() - tk0); TADD(4, 1); TADD(5, acc_dp); TADD(6, acc_dn); }
+    if (bounce == 1u) { TADD(0, acc_q); TADD(1, acc_p); TADD(2, acc_n); TADD(3, TSTAMP() - tk0); TADD(4, 1); TADD(5, acc_dp); TADD(6, acc_dn); TADD(7, acc_lc); }
 }
 
 // mean = sum / spp ; vec_rgb (common.rs:75-81); row-major frame or this rank's compact tile buffer

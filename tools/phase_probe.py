@@ -34,3 +34,4 @@ if t[2]:
           % (t[0] / t[2], t[1] / t[2], t[2], t[3] / max(t[4], 1), t[4]))
     print("   units whose rays are all dead (mix 0.0 parents): %d, process_ray %.0f cycles each; the others: %d, %.0f cycles each"
           % (t[6], t[5] / max(t[6], 1), t[2] - t[6], (t[1] - t[5]) / max(t[2] - t[6], 1)))
+    print("   of which closest_hit (lane 0's clock): %.0f cycles per unit with live rays" % (t[7] / max(t[2] - t[6], 1)))
