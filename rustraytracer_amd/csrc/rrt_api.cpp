@@ -381,7 +381,7 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
     if (!cam || !st) return fail(RRT_E_INVALID, "null camera/settings");
     if (st->width == 0 || st->height == 0 || st->spp == 0) return fail(RRT_E_INVALID, "width, height and spp must be > 0");
     if ((uint64_t)st->width * st->height > 0x7fffffffull) return fail(RRT_E_INVALID, "image too large");
-    if (st->max_bounce + 2 > (uint32_t)rrt::kMaxLevels) return fail(RRT_E_INVALID, "max_bounce too large (<= 16)");
+    if (st->max_bounce > (uint32_t)rrt::kMaxLevels - 2u) return fail(RRT_E_INVALID, "max_bounce too large (<= 16)");   // no addition: it would wrap
     if (st->tile_world == 0 || st->tile_rank >= st->tile_world) return fail(RRT_E_INVALID, "bad tile_rank/tile_world");
     rrt::DFrame& fr = out->fr;
     fr.cam = *cam;
@@ -741,6 +741,11 @@ int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint
                double* out_t, double* out_color) try {
     if (!s || !st) return fail(RRT_E_INVALID, "null argument");
     if (st->tile_world != 1) return fail(RRT_E_INVALID, "rrt_render needs tile_world == 1");
+    {
+        FramePlan probe;   // argument errors are reported before anything touches the device
+        const int prc = plan_frame(s, cam, st, &probe);
+        if (prc) return prc;
+    }
     HIP_TRY(hipSetDevice(s->device));
     const size_t npx = (size_t)st->width * st->height;
     if (out_rgb8) HIP_TRY(s->w_rgb.ensure(npx * 3));
@@ -772,7 +777,7 @@ int rrt_assemble_tiles(const void* d_gathered, uint32_t width, uint32_t height, 
 static int ray_query(rrt_scene* s, const double* rays, int64_t n, bool cast, uint32_t max_bounce, uint32_t prune,
                      int32_t* ent, int32_t* tri, double* t, double* pos, double* nrm, double* color) {
     if (!s || !rays || n < 0) return fail(RRT_E_INVALID, "bad argument");
-    if (cast && max_bounce + 2 > (uint32_t)rrt::kMaxLevels) return fail(RRT_E_INVALID, "max_bounce too large (<= 16)");
+    if (cast && max_bounce > (uint32_t)rrt::kMaxLevels - 2u) return fail(RRT_E_INVALID, "max_bounce too large (<= 16)");
     if (n == 0) return RRT_OK;
     int rc = commit(s);
     if (rc) return rc;

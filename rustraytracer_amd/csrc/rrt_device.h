@@ -152,7 +152,7 @@ struct DWork {
     double* samp;        // [P][3]          finished per-sample colour ...
     uint32_t* samp32;    // [P]             ... unless this says kSampTexel | sky texel (a primary ray that ended in the sky)
     double* accum;       // [3][npx_local]  running sum over samples
-    unsigned long long* stats;  // [0] rays traced, [1] traversal overflows
+    unsigned long long* stats;  // [8]: 0 bounce rays traced, 1 traversal overflows, 2 cull violations (mode 2), 3 zero-mix paths, 4+l rays of level l
     uint64_t cap;        // P
 };
 

@@ -417,7 +417,7 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
             // Software pipeline over the leaf's contiguous triangle stream, unrolled by two so the
             // prefetched triangle lands in the other register set (no copies): while A is tested B
             // is in flight and vice versa.  The prefetch may run up to two entries past the leaf:
-            // the next leaf's entries, or the two pad entries the host appends to both arrays.
+            // the next leaf's entries, or the kStreamPad pad entries the host appends to both arrays.
             TriData A = ld_tri(tp);
             for (int32_t k = 0; k < count; k += 2) {
                 const TriData B = ld_tri(tp + k + 1);
@@ -1445,6 +1445,7 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
     for (;;) {
         Closest c;
         if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, kNoLds, o, d, medium, &c, stats);
+        else if (sc.cull_mode == 1) closest_hit<1, GROUPS>(sc, kNoLds, o, d, medium, &c, stats);
         else closest_hit<2, GROUPS>(sc, kNoLds, o, d, medium, &c, stats);
         Hit h;
         finish_hit(sc, kNoLds, o, d, c, &h);

@@ -200,3 +200,22 @@ def test_rope_faces_touch(H):
             else:
                 theirs = t["boxes"][nb, 3 + a] if k < 3 else t["boxes"][nb, a]
                 assert theirs == mine
+
+
+def test_max_bounce_is_range_checked_before_any_launch(H):
+    """max_bounce + 2 levels must fit kMaxLevels = 18; the check may not wrap in u32 (0xFFFFFFFF is the
+    usual 'unlimited' idiom).  Reported as RRT_E_INVALID before the device is touched (this test has no GPU)."""
+    import ctypes as C
+    from rustraytracer_amd import binding as B
+    w = H.World()
+    cam = H.default_camera()
+    rgb = np.zeros((4, 4, 3), np.uint8)
+    rays = np.zeros((2, 6))
+    col = np.zeros((2, 3))
+    for mb in (17, 0xFFFFFFFE, 0xFFFFFFFF):
+        st = H.make_settings(4, 4, max_bounce=mb)
+        assert B.lib.rrt_render(w.h, C.byref(cam), C.byref(st), rgb.ctypes.data, None, None, None) == -1
+        assert b"max_bounce" in B.lib.rrt_last_error()
+        assert B.lib.rrt_render_device(w.h, C.byref(cam), C.byref(st), None, None, None, None, None) == -1
+        assert B.lib.rrt_cast_rays(w.h, rays.ctypes.data, 2, mb, 0, col.ctypes.data) == -1
+        assert b"max_bounce" in B.lib.rrt_last_error()
