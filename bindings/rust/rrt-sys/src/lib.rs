@@ -91,6 +91,10 @@ extern "C" {
     pub fn rrt_render_device(s: *mut rrt_scene, cam: *const rrt_camera, st: *const rrt_settings,
                              d_rgb8: *mut c_void, d_ids: *mut c_void, d_t: *mut c_void, d_color: *mut c_void,
                              stream: *mut c_void) -> c_int;
+    pub fn rrt_render_device_noalloc(s: *mut rrt_scene, cam: *const rrt_camera, st: *const rrt_settings,
+                                     d_rgb8: *mut c_void, d_ids: *mut c_void, d_t: *mut c_void, d_color: *mut c_void,
+                                     stream: *mut c_void) -> c_int;
+    pub fn rrt_noalloc_scratch_bytes() -> u64;
     pub fn rrt_tile_slots(width: u32, height: u32, tile_world: u32) -> i64;
     pub fn rrt_assemble_tiles(d_gathered: *const c_void, width: u32, height: u32, tile_world: u32,
                               d_rgb8: *mut c_void, stream: *mut c_void) -> c_int;

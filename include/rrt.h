@@ -203,6 +203,25 @@ int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint
 int rrt_render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids,
                       void* d_t, void* d_color, void* stream);
 
+/* NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, outputs and
+ * results (bit for bit) as rrt_render_device, but the call allocates nothing: no hipMalloc /
+ * hipFree, no event creation, no host container growth.  The wavefront work buffers (ray queues,
+ * level records, sample colours, running sums, queue counters, statistics) are carved out of a
+ * file-scope `static __device__` array of rrt_noalloc_scratch_bytes() = 256 MiB that every GPU the
+ * library runs on holds until the process ends.
+ *   - the scene must be committed (rrt_scene_commit) and unchanged since: otherwise RRT_E_STATE;
+ *   - the frame must fit: local pixels x (24 + bytes per path of ONE sample) <= the scratch, i.e.
+ *     about 690 k pixels per rank at max_bounce 2 (960x540 whole; 1080p from tile_world 4 up);
+ *     larger frames return RRT_E_NOMEM with the sizes in rrt_last_error().  spp is not limited:
+ *     samples are processed in as many batches as the scratch requires;
+ *   - all calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two
+ *     threads, two scenes) race.  Serialise them.  What must start at zero is cleared by the call;
+ *   - the frame is not timed: rrt_get_stats reports 0 for the *_ms fields (counters are valid). */
+int rrt_render_device_noalloc(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids,
+                              void* d_t, void* d_color, void* stream);
+uint64_t rrt_noalloc_scratch_bytes(void);
+
 /* Tiles each rank owns (padded to equal size so the gather is regular). */
 int64_t rrt_tile_slots(uint32_t width, uint32_t height, uint32_t tile_world);
 

@@ -43,7 +43,7 @@ EXPORTS = [
     "rrt_add_material", "rrt_add_material_ext", "rrt_add_sphere", "rrt_add_mesh", "rrt_add_group", "rrt_set_sky_face",
     "rrt_set_directional_light", "rrt_set_ambient", "rrt_set_work_budget", "rrt_set_cull_mode",
     "rrt_scene_commit",
-    "rrt_render", "rrt_render_device", "rrt_tile_slots", "rrt_assemble_tiles",
+    "rrt_render", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_assemble_tiles",
     "rrt_trace_rays", "rrt_cast_rays", "rrt_get_stats", "rrt_mesh_tree_sizes",
     "rrt_mesh_tree_export", "rrt_selftest_math", "rrt_philox4x32_10",
     "rrt_host_load_model", "rrt_host_add_model", "rrt_host_load_png_rgb8",
@@ -91,6 +91,8 @@ def _load():
     L.rrt_scene_commit.argtypes = [vp]
     L.rrt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp]
     L.rrt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp, vp]
+    L.rrt_render_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp, vp]
+    L.rrt_noalloc_scratch_bytes.restype = u64
     L.rrt_tile_slots.argtypes = [u32, u32, u32]
     L.rrt_tile_slots.restype = i64
     L.rrt_assemble_tiles.argtypes = [vp, u32, u32, u32, vp, vp]

@@ -132,6 +132,8 @@ struct rrt_scene {
     size_t timed_used = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     bool have_frame = false;
+    bool frame_timed = false;                   // the last frame recorded events (the no-alloc entry point does not)
+    const unsigned long long* stats_src = nullptr;   // device counters of the last frame (w_stats or the static scratch)
     rrt_stats stats{};
 
     ~rrt_scene() {
@@ -358,6 +360,11 @@ int commit(rrt_scene* s) {
         d.sky_w[f] = s->sky[f].w;
         d.sky_h[f] = s->sky[f].h;
     }
+    {
+        unsigned char* base = nullptr;   // set-up: this device's no-alloc scratch (rrt_render_device_noalloc)
+        const int e = rrt::scratch_base(s->device, &base);
+        if (e != 0) return fail(RRT_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString((hipError_t)e));
+    }
     s->dirty = false;
     return RRT_OK;
 }
@@ -377,7 +384,11 @@ size_t bytes_per_path(uint32_t levels) {
            + 2 * (6 * 8 + 4 + 4);   // two queues
 }
 
-int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, FramePlan* out) {
+// `budget`: bytes the batch's work buffers may take; `fixed_per_px`: bytes per local pixel that do not
+// scale with the batch (the no-alloc entry point counts its accum array here, the allocating one does
+// not: accum has always been outside rrt_set_work_budget).
+int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, FramePlan* out, uint64_t budget,
+               uint64_t fixed_per_px = 0) {
     if (!cam || !st) return fail(RRT_E_INVALID, "null camera/settings");
     if (st->width == 0 || st->height == 0 || st->spp == 0) return fail(RRT_E_INVALID, "width, height and spp must be > 0");
     if ((uint64_t)st->width * st->height > 0x7fffffffull) return fail(RRT_E_INVALID, "image too large");
@@ -401,9 +412,12 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
     fr.npx_local = fr.n_slots * 256u;
     out->levels = st->max_bounce + 2;
     const size_t bpp = bytes_per_path(out->levels);
-    uint64_t max_spp = s->work_budget / ((uint64_t)bpp * fr.npx_local);
-    if (st->batch_spp) max_spp = st->batch_spp;
-    if (max_spp == 0) return fail(RRT_E_NOMEM, "work budget too small for one sample per pixel (rrt_set_work_budget)");
+    const uint64_t fixed = fixed_per_px * fr.npx_local;
+    uint64_t max_spp = budget > fixed ? (budget - fixed) / ((uint64_t)bpp * fr.npx_local) : 0;
+    if (st->batch_spp && (fixed_per_px == 0 || st->batch_spp < max_spp)) max_spp = st->batch_spp;
+    if (max_spp == 0)
+        return fail(RRT_E_NOMEM, "work budget too small for one sample per pixel: " + std::to_string(fr.npx_local) +
+                                     " pixels x " + std::to_string(bpp + fixed_per_px) + " B > " + std::to_string(budget) + " B");
     // keep a path's byte offset in the work arrays (56 * path id) in 32 bits: the kernels address them that way
     max_spp = std::min<uint64_t>(max_spp, (0xffffffffull / (rrt::kRecDoubles * 8)) / fr.npx_local);
     if (max_spp == 0) return fail(RRT_E_NOMEM, "frame too large");
@@ -446,6 +460,39 @@ int ensure_work(rrt_scene* s, const FramePlan& pl, rrt::DWork* wk) {
     return RRT_OK;
 }
 
+// The same buffers carved out of one caller- or library-provided block (the no-alloc entry point:
+// the per-device static scratch array of rrt_kernels.hip).  No allocation; fails if the block is too small.
+constexpr uint64_t kCarveAlign = 256;
+uint64_t carve_bytes(const FramePlan& pl) {
+    const uint64_t P = pl.cap;
+    const uint64_t parts[] = {8 * 8, 2 * (rrt::kMaxLevels + 1) * 4, P * rrt::kRecDoubles * 8, P * rrt::kRecDoubles * 8,
+                              P * rrt::kRecDoubles * 8 * pl.levels, P * 3 * 8, P * 4, (uint64_t)pl.fr.npx_local * 3 * 8};
+    uint64_t total = 0;
+    for (uint64_t b : parts) total += (b + kCarveAlign - 1) / kCarveAlign * kCarveAlign;
+    return total;
+}
+int carve_work(unsigned char* base, uint64_t bytes, const FramePlan& pl, rrt::DWork* wk) {
+    if (carve_bytes(pl) > bytes)
+        return fail(RRT_E_NOMEM, "frame needs " + std::to_string(carve_bytes(pl)) + " B of scratch, the block has " + std::to_string(bytes));
+    const uint64_t P = pl.cap;
+    uint64_t off = 0;
+    const auto take = [&](uint64_t b) {
+        unsigned char* p = base + off;
+        off += (b + kCarveAlign - 1) / kCarveAlign * kCarveAlign;
+        return p;
+    };
+    wk->stats = (unsigned long long*)take(8 * 8);
+    wk->q_count = (uint32_t*)take(2 * (rrt::kMaxLevels + 1) * 4);
+    wk->q[0] = (double*)take(P * rrt::kRecDoubles * 8);
+    wk->q[1] = (double*)take(P * rrt::kRecDoubles * 8);
+    wk->rec = (double*)take(P * rrt::kRecDoubles * 8 * pl.levels);
+    wk->samp = (double*)take(P * 3 * 8);
+    wk->samp32 = (uint32_t*)take(P * 4);
+    wk->accum = (double*)take((uint64_t)pl.fr.npx_local * 3 * 8);
+    wk->cap = P;
+    return RRT_OK;
+}
+
 int timed_slot(rrt_scene* s, TimedLaunch** out) {
     if (s->timed_used == s->timed.size()) {
         TimedLaunch t;
@@ -457,53 +504,79 @@ int timed_slot(rrt_scene* s, TimedLaunch** out) {
     return RRT_OK;
 }
 
+// NOALLOC (rrt_render_device_noalloc): nothing here may allocate -- no hipMalloc/hipFree, no event
+// creation, no growth of a host container.  The work buffers are carved out of the device's static
+// scratch array, the scene must be committed already, and the frame is not timed.
+template <bool NOALLOC>
 int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids, void* d_t,
                   void* d_color, void* stream_v) {
     if (!s) return fail(RRT_E_INVALID, "null scene");
     FramePlan pl;
-    int rc = plan_frame(s, cam, st, &pl);
-    if (rc) return rc;
+    // the scratch block minus the two small headers; accum (24 B per pixel) is part of it
+    int rc = NOALLOC ? plan_frame(s, cam, st, &pl, rrt::kScratchBytes - 16 * kCarveAlign, 3 * 8) : plan_frame(s, cam, st, &pl, s->work_budget);
+    if (rc) {
+        if (NOALLOC && rc == RRT_E_NOMEM)
+            g_err = "rrt_render_device_noalloc: frame too large for the " + std::to_string(rrt::kScratchBytes >> 20) +
+                    " MiB static scratch (" + g_err + "); shard it (tile_world) or use rrt_render_device";
+        return rc;
+    }
     if (st->tile_world > 1 && (d_ids || d_t || d_color))
         return fail(RRT_E_INVALID, "AOV / f64 colour outputs need tile_world == 1");
-    rc = commit(s);
-    if (rc) return rc;
     rrt::DWork wk{};
-    rc = ensure_work(s, pl, &wk);
-    if (rc) return rc;
+    if (NOALLOC) {
+        if (s->dirty) return fail(RRT_E_STATE, "rrt_render_device_noalloc needs a committed scene (rrt_scene_commit uploads, i.e. allocates)");
+        HIP_TRY(hipSetDevice(s->device));
+        unsigned char* base = nullptr;
+        const int e = rrt::scratch_base(s->device, &base);
+        if (e != 0 || !base) return fail(RRT_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString((hipError_t)e));
+        rc = carve_work(base, rrt::kScratchBytes, pl, &wk);
+        if (rc) return rc;
+    } else {
+        rc = commit(s);
+        if (rc) return rc;
+        rc = ensure_work(s, pl, &wk);
+        if (rc) return rc;
+    }
     hipStream_t stream = (hipStream_t)stream_v;
-    if (!s->ev_begin) {
+    if (!NOALLOC && !s->ev_begin) {
         HIP_TRY(hipEventCreate(&s->ev_begin));
         HIP_TRY(hipEventCreate(&s->ev_end));
     }
     s->timed_used = 0;
-    HIP_TRY(hipEventRecord(s->ev_begin, stream));
+    s->frame_timed = !NOALLOC;
+    s->stats_src = wk.stats;
+    if (!NOALLOC) HIP_TRY(hipEventRecord(s->ev_begin, stream));
     HIP_TRY(hipMemsetAsync(wk.stats, 0, 8 * 8, stream));
     rrt::DFrame fr = pl.fr;
     for (uint32_t b = 0; b < pl.n_batches; ++b) {
         fr.s0 = b * pl.batch_spp;
         fr.ns = std::min(pl.batch_spp, st->spp - fr.s0);
         HIP_TRY(hipMemsetAsync(wk.q_count, 0, 2 * (rrt::kMaxLevels + 1) * 4, stream));
-        TimedLaunch* tl;
-        rc = timed_slot(s, &tl);
-        if (rc) return rc;
-        tl->primary = true;
-        tl->launches = 1;
-        HIP_TRY(hipEventRecord(tl->a, stream));
+        TimedLaunch* tl = nullptr;
+        if (!NOALLOC) {
+            rc = timed_slot(s, &tl);
+            if (rc) return rc;
+            tl->primary = true;
+            tl->launches = 1;
+            HIP_TRY(hipEventRecord(tl->a, stream));
+        }
         rrt::launch_primary(s->dscene, wk, fr, (int32_t*)d_ids, (double*)d_t, stream);
-        HIP_TRY(hipEventRecord(tl->b, stream));
-        // one event pair around the batch's bounce levels together (each hipEventRecord between two
-        // launches costs ~3 us of idle GPU: ten events a frame were 1.5 % of it)
-        rc = timed_slot(s, &tl);
-        if (rc) return rc;
-        tl->primary = false;
-        tl->launches = st->max_bounce + 1;
-        HIP_TRY(hipEventRecord(tl->a, stream));
+        if (!NOALLOC) {
+            HIP_TRY(hipEventRecord(tl->b, stream));
+            // one event pair around the batch's bounce levels together (each hipEventRecord between two
+            // launches costs ~3 us of idle GPU: ten events a frame were 1.5 % of it)
+            rc = timed_slot(s, &tl);
+            if (rc) return rc;
+            tl->primary = false;
+            tl->launches = st->max_bounce + 1;
+            HIP_TRY(hipEventRecord(tl->a, stream));
+        }
         for (uint32_t bounce = 1; bounce <= st->max_bounce + 1; ++bounce)
             rrt::launch_bounce(s->dscene, wk, fr, bounce, stream);
-        HIP_TRY(hipEventRecord(tl->b, stream));
+        if (!NOALLOC) HIP_TRY(hipEventRecord(tl->b, stream));
         rrt::launch_accumulate(wk, fr, b + 1 == pl.n_batches, (uint8_t*)d_rgb8, (double*)d_color, stream);   // the last one resolves
     }
-    HIP_TRY(hipEventRecord(s->ev_end, stream));
+    if (!NOALLOC) HIP_TRY(hipEventRecord(s->ev_end, stream));
     HIP_TRY(hipGetLastError());
     s->have_frame = true;
     s->stats = rrt_stats{};
@@ -523,6 +596,9 @@ const char* rrt_version(void) { return "rustraytracer_amd 0.1 (gfx950)"; }
 int rrt_set_device(int device) {
     HIP_TRY(hipSetDevice(device));
     g_device = device;
+    unsigned char* base = nullptr;   // set-up: resolve this device's copy of the no-alloc scratch array once
+    const int e = rrt::scratch_base(device, &base);
+    if (e != 0) return fail(RRT_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString((hipError_t)e));
     return RRT_OK;
 }
 
@@ -732,10 +808,19 @@ int64_t rrt_tile_slots(uint32_t width, uint32_t height, uint32_t tile_world) {
 
 int rrt_render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids, void* d_t,
                       void* d_color, void* stream) try {
-    return render_device(s, cam, st, d_rgb8, d_ids, d_t, d_color, stream);
+    return render_device<false>(s, cam, st, d_rgb8, d_ids, d_t, d_color, stream);
 } catch (...) {
     return on_exception();
 }
+
+int rrt_render_device_noalloc(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids,
+                              void* d_t, void* d_color, void* stream) try {
+    return render_device<true>(s, cam, st, d_rgb8, d_ids, d_t, d_color, stream);
+} catch (...) {
+    return on_exception();
+}
+
+uint64_t rrt_noalloc_scratch_bytes(void) { return rrt::kScratchBytes; }
 
 int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint8_t* out_rgb8, int32_t* out_ids,
                double* out_t, double* out_color) try {
@@ -743,7 +828,7 @@ int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint
     if (st->tile_world != 1) return fail(RRT_E_INVALID, "rrt_render needs tile_world == 1");
     {
         FramePlan probe;   // argument errors are reported before anything touches the device
-        const int prc = plan_frame(s, cam, st, &probe);
+        const int prc = plan_frame(s, cam, st, &probe, s->work_budget);
         if (prc) return prc;
     }
     HIP_TRY(hipSetDevice(s->device));
@@ -752,7 +837,7 @@ int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint
     if (out_ids) HIP_TRY(s->w_ids.ensure(npx * 8));
     if (out_t) HIP_TRY(s->w_t.ensure(npx * 8));
     if (out_color) HIP_TRY(s->w_color.ensure(npx * 24));
-    int rc = render_device(s, cam, st, out_rgb8 ? s->w_rgb.p : nullptr, out_ids ? s->w_ids.p : nullptr,
+    int rc = render_device<false>(s, cam, st, out_rgb8 ? s->w_rgb.p : nullptr, out_ids ? s->w_ids.p : nullptr,
                            out_t ? s->w_t.p : nullptr, out_color ? s->w_color.p : nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -831,9 +916,13 @@ int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) try {
     if (!s || !out) return fail(RRT_E_INVALID, "null argument");
     if (!s->have_frame) return fail(RRT_E_STATE, "no frame rendered yet");
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipEventSynchronize(s->ev_end));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
+    if (s->frame_timed) {
+        HIP_TRY(hipEventSynchronize(s->ev_end));
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
+    } else {
+        HIP_TRY(hipDeviceSynchronize());   // an untimed (no-alloc) frame: wait for its stream the blunt way
+    }
     s->stats.gpu_ms = ms;
     double prim = 0.0, bnc = 0.0;
     uint32_t nprim = 0, nbnc = 0;
@@ -848,7 +937,7 @@ int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) try {
     s->stats.primary_kernel_launches = nprim;
     s->stats.bounce_kernel_launches = nbnc;
     unsigned long long dev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(dev, s->w_stats.p, sizeof(dev), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dev, s->stats_src, sizeof(dev), hipMemcpyDeviceToHost));
     s->stats.rays_traced = s->stats.primary_rays + dev[0];
     s->stats.traversal_overflow = dev[1];
     s->stats.cull_violations = dev[2];

@@ -180,6 +180,13 @@ void launch_cast_rays(const DScene& sc, const double* d_rays, int64_t n, uint32_
                       double* color, unsigned long long* stats, void* stream);
 void launch_selftest(int op, const double* a, const double* b, int64_t n, double* out, void* stream);
 
+// Scratch of the entry point that allocates nothing (rrt_render_device_noalloc): a file-scope
+// `static __device__` array in rrt_kernels.hip; every GPU the library runs on holds its own copy
+// until the process ends.  scratch_base resolves the current device's copy ONCE per device
+// (hipGetSymbolAddress, device `device` must be current) and returns 0 or the hipError_t.
+constexpr uint64_t kScratchBytes = 256ull << 20;
+int scratch_base(int device, unsigned char** ptr);
+
 void debug_phases(unsigned long long out[32]);   // zeros unless built with -DRRT_PROBE=1
 void philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "rrt_device.h"
@@ -1546,6 +1547,35 @@ void launch_selftest(int op, const double* a, const double* b, int64_t n, double
     hipLaunchKernelGGL(k_selftest, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, n,
                        out);
 }
+// ---------------------------------------------------------------------------
+// Scratch of rrt_render_device_noalloc.  In host code `scratch` is only a stand-in for the symbol,
+// not a device address: it is never passed to a kernel or a memset.  The address of each device's
+// copy is looked up once (per device, with that device current) and kept; every use goes through it.
+// ---------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+constexpr int kMaxDevices = 64;
+static unsigned char* g_scratch_ptr[kMaxDevices];      // 0 = not resolved yet
+static std::mutex g_scratch_mu;
+
+int scratch_base(int device, unsigned char** ptr) {
+    *ptr = nullptr;
+    if (device < 0 || device >= kMaxDevices) return (int)hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        int cur = -1;
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess) return (int)e;
+        if (cur != device) return (int)hipErrorInvalidDevice;       // the caller makes `device` current first
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!p) return (int)hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *ptr = g_scratch_ptr[device];
+    return 0;
+}
+
 void debug_phases(unsigned long long out[32]) {
 #if RRT_PROBE
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), 32 * sizeof(unsigned long long));

@@ -184,6 +184,11 @@ class World:
         cam = camera or default_camera()
         B.check(B.lib.rrt_render_device(self.h, C.byref(cam), C.byref(settings), d_rgb8, d_ids, d_t, d_color, stream))
 
+    def render_device_noalloc(self, settings, d_rgb8, d_ids=None, d_t=None, d_color=None, stream=None, camera=None):
+        """rrt_render_device_noalloc: same, over the library's static scratch (allocates nothing)."""
+        cam = camera or default_camera()
+        B.check(B.lib.rrt_render_device_noalloc(self.h, C.byref(cam), C.byref(settings), d_rgb8, d_ids, d_t, d_color, stream))
+
     def stats(self):
         st = B.Stats()
         B.check(B.lib.rrt_get_stats(self.h, C.byref(st)))

@@ -1,0 +1,102 @@
+"""rrt_render_device_noalloc (include/rrt.h): the entry point that allocates nothing.
+
+It has no counterpart in the reference; it serves callers that cannot call hipMalloc (HIP graph
+capture, tight serving loops).  Its wavefront work buffers live in a file-scope `static __device__`
+array of the library instead of hipMalloc'ed memory, so its results must equal rrt_render_device's bit
+for bit -- checked here through the C ABI on two calls in a row, the second with a smaller input (the
+array keeps the first call's contents: anything not cleared or overwritten would show), then on a
+sharded frame and a multi-batch frame, and on the error paths (frame too large, scene not committed).
+Collected last (test_zz_*): the round-end run uses `pytest -x`.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(H, g, w, h, **kw):
+    """Renders the same settings through rrt_render_device and rrt_render_device_noalloc."""
+    import torch
+    st = H.make_settings(w, h, **kw)
+    outs = []
+    for fn in (g.render_device, g.render_device_noalloc):
+        rgb = torch.full((h, w, 3), 77, dtype=torch.uint8, device="cuda:0")
+        ids = torch.full((h, w, 2), -2, dtype=torch.int32, device="cuda:0")
+        t = torch.full((h, w), -1.0, dtype=torch.float64, device="cuda:0")
+        col = torch.full((h, w, 3), -1.0, dtype=torch.float64, device="cuda:0")
+        fn(st, rgb.data_ptr(), ids.data_ptr(), t.data_ptr(), col.data_ptr())
+        torch.cuda.synchronize()
+        stats = g.stats()
+        outs.append((rgb.cpu().numpy(), ids.cpu().numpy(), t.cpu().numpy(), col.cpu().numpy(), stats))
+    return outs
+
+
+def _check(a, b):
+    for x, y, name in zip(a[:4], b[:4], ("rgb", "ids", "t", "color")):
+        assert np.array_equal(x, y), name
+    assert np.array_equal(a[3].view(np.uint64), b[3].view(np.uint64))          # signed zeros included
+    for k in ("rays_traced", "paths", "traversal_overflow", "level_rays", "zero_mix_paths", "n_batches"):
+        if k != "n_batches":
+            assert a[4][k] == b[4][k], k
+    assert b[4]["gpu_ms"] == 0.0 and b[4]["primary_kernel_ms"] == 0.0         # the no-alloc frame is not timed
+
+
+def test_noalloc_equals_render_device_twice_second_smaller(H, O, scenes):
+    from rustraytracer_amd import binding as B
+    assert B.lib.rrt_noalloc_scratch_bytes() == 256 << 20
+    g = scenes.main_rs_scene(H.World(device=0), H.loaders)
+    c = scenes.main_rs_scene(O.OracleScene(), O)
+    g.commit()
+    # first call: 960x540, 3 spp -> the scratch holds 1 spp per batch of this frame (3 batches)
+    big = _both(H, g, 960, 540, spp=3, seed=5)
+    _check(*big)
+    assert big[1][4]["n_batches"] >= 2
+    co = c.render(960, 540, spp=3, seed=5)
+    assert np.array_equal(big[1][0], co["rgb"]) and np.array_equal(big[1][3], co["color"])
+    assert np.array_equal(big[1][1], co["ids"]) and np.array_equal(big[1][2], co["t"])
+    # second call, smaller input, ragged size: stale queue entries / counters / samples of the first
+    # call are still in the array
+    small = _both(H, g, 203, 117, spp=2, seed=9, max_bounce=4)
+    _check(*small)
+    co = c.render(203, 117, spp=2, seed=9, max_bounce=4)
+    assert np.array_equal(small[1][0], co["rgb"]) and np.array_equal(small[1][3], co["color"])
+    # and a third, with the diffuse-bounce lobe (RNG keyed by pixel/sample, independent of the batching)
+    g4 = scenes.cfg4_scene(H.World(device=0), H.loaders)
+    g4.commit()
+    _check(*_both(H, g4, 480, 270, spp=4, seed=3))
+
+
+def test_noalloc_sharded_frame_and_limits(H, scenes):
+    import torch
+    from rustraytracer_amd import binding as B
+    g = scenes.main_rs_scene(H.World(device=0), H.loaders)
+    cam = H.default_camera()
+    st = H.make_settings(64, 64)
+    out = torch.zeros((64, 64, 3), dtype=torch.uint8, device="cuda:0")
+    # not committed yet: committing uploads (allocates), which this entry point may not do
+    assert B.lib.rrt_render_device_noalloc(g.h, C.byref(cam), C.byref(st), out.data_ptr(), None, None, None, None) == -3
+    assert b"committed" in B.lib.rrt_last_error()
+    g.commit()
+    # 1080p does not fit whole (2.07 M pixels x 388 B > 256 MiB): a clear error, nothing launched
+    st = H.make_settings(1920, 1080, spp=2)
+    big = torch.zeros((1080, 1920, 3), dtype=torch.uint8, device="cuda:0")
+    assert B.lib.rrt_render_device_noalloc(g.h, C.byref(cam), C.byref(st), big.data_ptr(), None, None, None, None) == -4
+    msg = B.lib.rrt_last_error().decode()
+    assert "too large" in msg and "256 MiB" in msg
+    # ... but its shards do: tile_world 4, each rank's compact tile buffer equals rrt_render_device's
+    world = 4
+    slots = H.tile_slots(1920, 1080, world)
+    for r in (0, 3):
+        st = H.make_settings(1920, 1080, spp=2, seed=1, tile_rank=r, tile_world=world)
+        a = torch.zeros((slots, 8, 32, 3), dtype=torch.uint8, device="cuda:0")
+        b = torch.zeros((slots, 8, 32, 3), dtype=torch.uint8, device="cuda:0")
+        g.render_device(st, a.data_ptr())
+        g.render_device_noalloc(st, b.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), r
+    # a changed scene is dirty again
+    g.set_ambient(0.2)
+    st = H.make_settings(64, 64)
+    assert B.lib.rrt_render_device_noalloc(g.h, C.byref(cam), C.byref(st), out.data_ptr(), None, None, None, None) == -3
