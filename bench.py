@@ -5,38 +5,51 @@
 
 One "step" = one full pass of the hot path (primary rays -> closest hit ->
 shading -> reflection bounces -> sky lookup -> accumulate -> quantise, and for
-N > 1 the framebuffer gather over RCCL + de-interleave) over BASELINE.json's
-configs[1]: the main.rs world (ufo_fix.obj kd-tree + 2 spheres) under the
-blue_sunset cubemap at 1920x1080, 16 spp.  The scene is resident in HBM before
-the timed region.  Rank 0 prints ONE JSON line.
+N > 1 the framebuffer gather over RCCL + de-interleave) over one frame.  The
+scene is resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+N = 1 (the contract's bench line): BASELINE.json configs[1] -- the main.rs world
+(ufo_fix.obj kd-tree + 2 spheres) under the blue_sunset cubemap at 1920x1080,
+16 spp.  `--config cfg5` runs configs[4] (2M-triangle mesh, the HBM-bound
+config) with its own roofline and cpu_baseline; the other configs print the
+same line without them.
+
+N > 1: without WORLD_SIZE in the environment the script starts its N ranks
+itself (a child `python -m torch.distributed.run`, before anything touches the
+GPU); under torch.distributed.run it is one rank.  Default = STRONG scaling on
+north_star's target frame: the same scene at 1920x1080, 64 spp IN TOTAL whatever
+N is; the image's 32x8 tiles are dealt round-robin over the ranks, each renders
+its tiles at 64 spp, one all-gather of the compact RGB8 tile buffers (6.2 MB in
+total) and a de-interleave end the step; the gather of frame i overlaps the
+render of frame i+1 (second stream, double-buffered tile buffers).  The weak
+figure (16*N spp, one 1080p/16spp frame of samples per GPU) is measured in the
+same run and printed beside it (`weak`); `--scaling weak` swaps the two.
 
 Metric: Mrays/s, whole job.  A ray = one world-level closest-hit query (one
 `RayTracer::cast`, src/tracer.rs:177) actually executed on the GPU, with
 reference semantics (prune_zero_mix = 0: the reflection ray is cast even when
 its mix is 0.0, as src/tracer.rs:195-201 does).
 
-Multi-GPU (weak scaling, the default): the image's 32x8 tiles are dealt
-round-robin over the ranks and the frame is rendered at 16*N spp, so each GPU
-keeps one 1080p/16spp frame's worth of samples per step; one all-gather of the
-compact RGB8 tile buffers (1080p: 6.2 MB in total) and a de-interleave on every
-rank end the step.  --scaling strong keeps 16 spp in total instead.
+Timing: W warm-up steps, then blocks of exactly K steps, each bracketed by a
+barrier + torch.cuda.synchronize() on both sides and reduced with MAX over the
+ranks; blocks repeat until 0.5 s of them have been timed.  `value` and
+`ms_per_step` come from the MEDIAN block; `timing` carries min / median / max.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402  (first: brings the process's HIP runtime)
-import torch.distributed as dist  # noqa: E402
-
 W, H, SPP = 1920, 1080, 16
+STRONG_SPP = 64                      # north_star: "ufo.obj kd-tree at 1080p/64spp"
 
-# --config: the other BASELINE.json configs (parity-test cases; measured for the table in DESIGN.md,
-# not the contract's bench line, which is cfg2).  name -> (scene function, W, H, spp, max_bounce, what)
+# --config: name -> (scene function, W, H, spp, max_bounce, what)
 CONFIGS = {
     "cfg1": ("cfg1_scene", 640, 480, 1, 2, "configs[0]: cube.obj + 3 spheres, sky cubemap, 640x480, 1 spp"),
     "cfg2": ("cfg2_scene", W, H, SPP, 2, "configs[1]"),
@@ -48,89 +61,183 @@ CONFIGS = {
     "cfg5": ("cfg5_scene", 1920, 1080, 64, 2, "configs[4]: synthetic 2M-triangle height field, diffuse bounces, 1920x1080, 64 spp (extension lobes)"),
 }
 
-# Algorithmic work per ray for the roofline (DESIGN.md "Measurement"): sizes of the
-# device layout in csrc/rrt_device.h and flop counts of SURVEY §8(d).
-S_NODE, S_LEAF, S_TRI, S_HITN = 16, 88, 76, 24     # bytes: interior step / leaf header / triangle test / winner's normal
+# Algorithmic work per ray for the rooflines -- the constants frozen in BASELINE.md section 3.
+# Bytes are sizes of the device layout (csrc/rrt_device.h); flops are SURVEY 8(d)'s.
+S_NODE, S_LEAF, S_BOX32, S_TRI, S_WIN = 16, 80, 24, 72, 28   # DNodeI / DLeaf / DBox32 / DTri / winner's leaf_ref + normal
 F_TRI, F_BOX, F_NODE, F_SHADE, F_SPHERE = 53, 30, 1, 120, 25
+B_SKY, B_CONT, B_DEAD = 7, 116, 24   # HBM I/O of a primary ray: ends in the sky / continues / extra when its reflection is dead
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PEAK_F64_TFLOPS = 78.6      # vector FP64 (FMA-counted; this path may not contract FMAs)
+PEAK_F64_TFLOPS = 78.6      # vector FP64, FMA-counted (this path may not contract FMAs: its own ceiling is half of it)
+MIN_TIMED_SECONDS = 0.5
 
 
-def cpu_leg(n_threads, row_stride=1):
-    """Times the CPU oracle (a port of the reference, oracle/) on a bounded,
-    strided-row sample of the same workload and counts the per-ray traversal
-    work that prices the roofline."""
-    import numpy as np
-    from oracle import oracle as O
-    from rustraytracer_amd import scenes
-    cpu = scenes.cfg2_scene(O.OracleScene(), O)
-    cpu.render(W, H, spp=1, n_threads=n_threads, y0=0, y1=64, want=())            # warm
-    dt, frames, c = 0.0, 0, None
-    while dt < 2.0 and frames < 16:      # >= 2 s of wall time on n_threads cores (~30 core-seconds)
-        t0 = time.perf_counter()
-        out = cpu.render(W, H, spp=SPP, seed=0, n_threads=n_threads, y0=3, row_stride=row_stride, want=())
-        dt += time.perf_counter() - t0
-        frames += 1
-        c = dict(zip(O.COUNTER_NAMES, (int(x) for x in out["counters"])))
-    # the reference's own work split (SURVEY 8d "faithful" mode): 12 threads over 12 contiguous row-major
-    # chunks of W*H/12 pixels (tracer.rs:117-158) -- the slowest chunk sets the time
-    O.lib().orc_set_static_chunks(1)
-    t0 = time.perf_counter()
-    outf = cpu.render(W, H, spp=SPP, seed=0, n_threads=12, want=())
-    dtf = time.perf_counter() - t0
-    O.lib().orc_set_static_chunks(0)
-    faithful = {"value": int(outf["counters"][0]) / dtf / 1e6, "unit": "Mrays/s", "threads": 12,
-                "sample": "one full %dx%d frame at %d spp in 12 static contiguous pixel chunks as tracer.rs:117-158: "
-                          "%d rays in %.2f s" % (W, H, SPP, int(outf["counters"][0]), dtf)}
-    rows = len(range(3, H, row_stride))
-    # per-primary-ray traversal work: closest-hit of the sample-0 primary rays of those rows
-    import ctypes as C
-    st = O.Settings(W, H, 1, 2, 0, 0, 1)
-    cam = O.default_camera()
-    ys = list(range(3, H, row_stride))
-    rays = np.zeros((len(ys) * W, 6))
-    r = np.zeros(6)
-    L = O.lib()
-    k = 0
-    for y in ys[::32]:
-        for x in range(W):
-            L.orc_primary_ray(C.byref(cam), C.byref(st), x, y, 0, r.ctypes.data)
-            rays[k] = r
-            k += 1
-    pc = dict(zip(O.COUNTER_NAMES, (int(x) for x in cpu.trace_rays(rays[:k])["counters"])))
-    return {
-        "value": c["rays"] * frames / dt / 1e6, "unit": "Mrays/s", "cores": n_threads, "kind": "port",
-        "sample": "rows 3..%d step %d of the %dx%d frame (%d rows), %d spp, rendered %d times: %d rays in %.2f s; "
-                  "C++ f64 restatement of the reference, rows handed to threads dynamically (no per-hit Material "
-                  "clone: optimistic for the Rust binary)" % (H - 1, row_stride, W, H, rows, SPP, frames,
-                                                              c["rays"] * frames, dt),
-        "reference_work_split": faithful,
-    }, c, pc, k
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: which figure is `value` (the other is printed beside it)")
     ap.add_argument("--prune", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rank-share", action="store_true", help="skip the N = 1 strong-scaling rehearsal (tile_world 8 on one GPU)")
+    ap.add_argument("--once", action="store_true", help="time ONE block of --steps (profiler runs)")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--batch-spp", type=int, default=0, help="samples per pixel per wavefront batch (0 = from the work budget)")
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2",
-                    help="BASELINE.json config to run (default cfg2 = the contract's workload; the others "
-                         "print the same line without roofline/cpu_baseline)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel")
     ap.add_argument("--budget-gib", type=float, default=0.0, help="work-buffer budget in GiB (0 = library default)")
     ap.add_argument("--cull-mode", type=int, default=-1, help="rrt_set_cull_mode (0 off, 1 on, 2 verify; -1 = library default)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` on its own: start the N ranks as a fresh child process (never exec: this
+    process may not replace itself once a GPU runtime is loaded, and nothing has touched the GPU yet)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd).returncode)
+
+
+def median(v):
+    s = sorted(v)
+    n = len(s)
+    return s[n // 2] if n % 2 else 0.5 * (s[n // 2 - 1] + s[n // 2])
+
+
+# ---------------------------------------------------------------------------
+# CPU leg: times the oracle (a port of the reference, oracle/) on a bounded sample of the same
+# workload and counts the per-primary-ray traversal work that prices the rooflines.
+# ---------------------------------------------------------------------------
+def cpu_leg(config, n_threads, w, h, spp, max_bounce):
+    import ctypes as C
+    import numpy as np
+    from oracle import oracle as O
+    from rustraytracer_amd import scenes
+    L = O.lib()
+    t0 = time.perf_counter()
+    cpu = getattr(scenes, CONFIGS[config][0])(O.OracleScene(), O)
+    build_s = time.perf_counter() - t0
+    # a strided-row sample sized for ~2-4 s of wall time on n_threads cores (30-60 core-seconds)
+    cpu.render(w, h, spp=1, max_bounce=max_bounce, n_threads=n_threads, y0=0, y1=32, want=())            # warm
+    t0 = time.perf_counter()
+    probe = cpu.render(w, h, spp=1, max_bounce=max_bounce, n_threads=n_threads, y0=5, row_stride=54, want=())   # 20 rows
+    rate = int(probe["counters"][0]) / (time.perf_counter() - t0)        # rays/s, rough
+    rays_frame = int(probe["counters"][0]) / 20.0 * h * spp
+    stride = 1 if config == "cfg2" else max(1, int(rays_frame / (rate * 3.0)))
+    dt, frames, c = 0.0, 0, None
+    while dt < 2.0 and frames < 16:
+        t0 = time.perf_counter()
+        out = cpu.render(w, h, spp=spp, max_bounce=max_bounce, seed=0, n_threads=n_threads, y0=3, row_stride=stride, want=())
+        dt += time.perf_counter() - t0
+        frames += 1
+        c = dict(zip(O.COUNTER_NAMES, (int(x) for x in out["counters"])))
+    rows = len(range(3, h, stride))
+    base = {
+        "value": c["rays"] * frames / dt / 1e6, "unit": "Mrays/s", "cores": n_threads, "kind": "port",
+        "sample": "rows 3..%d step %d of the %dx%d frame (%d rows), %d spp, rendered %d times: %d rays in %.2f s; "
+                  "C++ f64 restatement of the reference, rows handed to threads dynamically (no per-hit Material "
+                  "clone: optimistic for the Rust binary); scene + kd-tree build %.1f s, not timed"
+                  % (h - 1, stride, w, h, rows, spp, frames, c["rays"] * frames, dt, build_s),
+    }
+    if config == "cfg2":
+        # the reference's own work split (SURVEY 8d "faithful" mode): 12 threads over 12 contiguous row-major
+        # chunks of W*H/12 pixels (tracer.rs:117-158) -- the slowest chunk sets the time
+        L.orc_set_static_chunks(1)
+        t0 = time.perf_counter()
+        outf = cpu.render(w, h, spp=spp, seed=0, n_threads=12, want=())
+        dtf = time.perf_counter() - t0
+        L.orc_set_static_chunks(0)
+        base["reference_work_split"] = {
+            "value": int(outf["counters"][0]) / dtf / 1e6, "unit": "Mrays/s", "threads": 12,
+            "sample": "one full %dx%d frame at %d spp in 12 static contiguous pixel chunks as tracer.rs:117-158: "
+                      "%d rays in %.2f s" % (w, h, spp, int(outf["counters"][0]), dtf)}
+    # per-primary-ray traversal work: closest hit of the sample-0 primary rays of every 32nd row
+    st = O.Settings(w, h, 1, max_bounce, 0, 0, 1)
+    cam = O.default_camera()
+    ys = np.ascontiguousarray(list(range(3, h, 32)), dtype=np.int32)          # 34 rows of a 1080-row frame
+    rays = np.zeros((len(ys) * w, 6))
+    L.orc_primary_rays_rows(C.byref(cam), C.byref(st), ys.ctypes.data, len(ys), 0, rays.ctypes.data)
+    L.orc_set_count_box_hits(1)
+    tr = cpu.trace_rays(rays)
+    L.orc_set_count_box_hits(0)
+    pc = dict(zip(O.COUNTER_NAMES, (int(x) for x in tr["counters"])))
+    n = float(len(rays))
+    per = {k: pc[k] / n for k in ("node_steps", "leaf_visits", "tri_tests", "sphere_tests", "box_tests", "tri_box_hits")}
+    per["hit_fraction"] = float((tr["ent"] >= 0).sum()) / n
+    per["mesh_hit_fraction"] = float((tr["tri"] >= 0).sum()) / n
+    per["sampled_primary_rays"] = int(n)
+    return base, per
+
+
+def flops_per_ray(per):
+    """N_tri*53 + N_box*30 + N_node*1 + N_sphere*25 + 120 (the reference's arithmetic:
+    every triangle of a visited leaf is tested; what the cull saves is not subtracted)."""
+    return (per["tri_tests"] * F_TRI + per["box_tests"] * F_BOX + per["node_steps"] * F_NODE
+            + per["sphere_tests"] * F_SPHERE + F_SHADE)
+
+
+def io_bytes_per_ray(stats):
+    """HBM I/O a primary ray cannot avoid: 3 B texel in + 4 B compact sample out when
+    it ends in the sky; 56 B level record + 56 B queue entry + 4 B sample tag when the path continues, + 24 B
+    advance sample when the continuation ray is dead (mix 0.0)."""
+    lv = stats["level_rays"]
+    cont = lv[1] / max(lv[0], 1)
+    dead = stats["zero_mix_paths"] / max(lv[0], 1)
+    return (1.0 - cont) * B_SKY + cont * B_CONT + dead * B_DEAD, cont, dead
+
+
+def traversal_bytes_per_ray(per):
+    """descent steps x 16 B + leaves x 80 B + listed triangles x 24 B (the cull box the
+    kernel reads in place of the triangle) + triangles whose own box the ray crosses x 72 B (the exact test no
+    box cull can avoid) + 28 B for a mesh hit (triangle id + normal)."""
+    return (per["node_steps"] * S_NODE + per["leaf_visits"] * S_LEAF + per["tri_tests"] * S_BOX32
+            + per["tri_box_hits"] * S_TRI + per["mesh_hit_fraction"] * S_WIN)
+
+
+def attach_profiles(roof, config):
+    """PMC traffic / SQ issue figures of the previous collection (tools/collect_all.sh -> profiles/)."""
+    sfx = "" if config == "cfg2" else "_" + config
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic%s.json" % sfx)
+    traffic = None
+    if os.path.exists(tf):
+        try:
+            t = json.load(open(tf)).get("k_wave_primary")
+            if t:
+                traffic = t["hbm_bytes_per_launch"]
+                roof["traffic_source"] = "profiles/pmc_traffic%s.json: %s" % (sfx, t.get("source"))
+        except (ValueError, KeyError):
+            pass
+    vf = os.path.join(ROOT, "profiles", "valu_busy%s.json" % sfx)
+    if os.path.exists(vf):
+        try:
+            v = json.load(open(vf)).get("k_wave_primary")
+            if v:
+                roof["executed"] = {"valu_busy": v["valu_busy"], "lane_utilisation": v["lane_utilisation"],
+                                    "issue_slot_frac": v["valu_busy"] * (v["lane_utilisation"] or 0.0),
+                                    "waves_per_simd": v["waves_per_simd"], "avg_launch_ns": v["avg_launch_ns"],
+                                    "source": "profiles/valu_busy%s.json: %s" % (sfx, v.get("source"))}
+        except (ValueError, KeyError):
+            pass
+    return traffic
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
+
+    import torch                          # first: brings the process's HIP runtime
+    import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        sys.exit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     # Rehearsal of the N-rank path on a box with fewer GPUs (never used by the driver):
     # RRT_BENCH_DEVICE pins every rank to one device, RRT_BENCH_BACKEND=gloo stages the gather through the host.
     backend = os.environ.get("RRT_BENCH_BACKEND", "nccl")
@@ -144,148 +251,210 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from rustraytracer_amd import host as Hst, scenes
-    global W, H, SPP
-    scene_fn, W, H, SPP, max_bounce, what = CONFIGS[args.config]
+    from rustraytracer_amd import host as Hst, scenes, distributed as D
+    scene_fn, w, h, spp0, max_bounce, what = CONFIGS[args.config]
+    if args.spp > 0:
+        spp0 = args.spp
     scene = getattr(scenes, scene_fn)(Hst.World(device=local_rank), Hst.loaders)
     if args.budget_gib > 0:
         scene.set_work_budget(int(args.budget_gib * (1 << 30)))
     if args.cull_mode >= 0:
         scene.set_cull_mode(args.cull_mode)
     scene.commit()                                   # scene resident in HBM before timing
-    spp = SPP * world if args.scaling == "weak" else SPP
-    st = Hst.make_settings(W, H, spp=spp, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune,
-                           tile_rank=rank, tile_world=world, batch_spp=args.batch_spp)
-    from rustraytracer_amd import distributed as D
-    frame = torch.empty((H, W, 3), dtype=torch.uint8, device=dev)
-    if world > 1:
-        local, gathered = D.alloc_tile_buffers(W, H, world, dev)
 
-    def step():
-        stream = torch.cuda.current_stream().cuda_stream
-        if world == 1:
-            scene.render_device(st, frame.data_ptr(), stream=stream)
-        else:
-            scene.render_device(st, local.data_ptr(), stream=stream)
-            D.gather_tiles(local, gathered)
-            Hst.assemble_tiles(gathered.data_ptr(), W, H, world, frame.data_ptr(), stream=stream)
+    frame = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+    pipe = D.TilePipeline(scene, w, h, world, dev, frame) if world > 1 else None
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    prim_ms = bnc_ms = 0.0
-    prim_n = bnc_n = 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    stats = scene.stats()                             # per-kernel hipEvent timings of the last timed step
-    prim_ms, prim_n = stats["primary_kernel_ms"], stats["primary_kernel_launches"]
-    bnc_ms, bnc_n = stats["bounce_kernel_ms"], stats["bounce_kernel_launches"]
+    def measure(spp_total):
+        """-> (list of block seconds [max over ranks], stats of this rank's last frame)"""
+        st = Hst.make_settings(w, h, spp=spp_total, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune,
+                               tile_rank=rank, tile_world=world, batch_spp=args.batch_spp)
 
+        def step():
+            if world == 1:
+                scene.render_device(st, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            else:
+                pipe.step(st)
+
+        for _ in range(args.warmup):
+            step()
+        blocks, total = [], 0.0
+        while True:
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+                torch.cuda.synchronize()
+            dt = D.max_over_ranks(time.perf_counter() - t0, dev)     # the same value on every rank: the loop ends together
+            blocks.append(dt)
+            total += dt
+            if args.once or total >= MIN_TIMED_SECONDS or len(blocks) >= 500:
+                break
+        return blocks, scene.stats()
+
+    def figure(spp_total):
+        blocks, stats = measure(spp_total)
+        rays_step, paths_step, overflow = D.sum_over_ranks(
+            [stats["rays_traced"], stats["paths"], stats["traversal_overflow"]], dev)
+        med = median(blocks)
+        return {"value": rays_step * args.steps / med / 1e6, "ms_per_step": med / args.steps * 1e3, "spp_total": spp_total,
+                "rays_per_step": rays_step, "samples_per_step": paths_step, "traversal_overflow": overflow,
+                "timing": {"blocks": len(blocks), "steps_per_block": args.steps,
+                           "ms_per_step_min": min(blocks) / args.steps * 1e3, "ms_per_step_median": med / args.steps * 1e3,
+                           "ms_per_step_max": max(blocks) / args.steps * 1e3}}, stats
+
+    other = None
+    if world == 1:
+        main_fig, stats = figure(spp0)
+        scaling = "strong"                    # one GPU: the distinction is empty; N > 1 defaults to strong
+    else:
+        spp_strong, spp_weak = (STRONG_SPP if args.config == "cfg2" and not args.spp else spp0), spp0 * world
+        strong, stats_s = figure(spp_strong)
+        weak, stats_w = figure(spp_weak)
+        scaling = args.scaling
+        main_fig, stats, other = (strong, stats_s, weak) if scaling == "strong" else (weak, stats_w, strong)
+
+    # ---- N = 1 extras -----------------------------------------------------------------------------------
     host_ms = None
     if world == 1:
         # PCIe-inclusive variant (never `value`): rrt_render into host memory = the same frame + one D2H copy
         import numpy as np
         import ctypes as C
         from rustraytracer_amd import binding as B
-        rgb = np.zeros((H, W, 3), np.uint8)
+        rgb = np.zeros((h, w, 3), np.uint8)
         cam = Hst.default_camera()
+        st = Hst.make_settings(w, h, spp=spp0, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune, batch_spp=args.batch_spp)
         n_host = max(2, min(args.steps, 5))
         for it in range(n_host + 1):
             if it == 1:
                 th = time.perf_counter()
             B.check(B.lib.rrt_render(scene.h, C.byref(cam), C.byref(st), rgb.ctypes.data_as(C.c_void_p), None, None, None))
         host_ms = (time.perf_counter() - th) / n_host * 1e3
+        # restore the stats of a device frame (rrt_render overwrote them with identical counters; timings differ)
+        scene.render_device(st, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        stats = scene.stats()
 
-    dt = D.max_over_ranks(dt, dev)
-    rays_step, paths_step, overflow = D.sum_over_ranks(
-        [stats["rays_traced"], stats["paths"], stats["traversal_overflow"]], dev)
+    rank_share = None
+    if world == 1 and args.config == "cfg2" and not args.no_rank_share and not args.once:
+        # Strong-scaling rehearsal on one GPU (no 8-GPU node is guaranteed): the target frame (1080p, 64 spp) as the
+        # 8 ranks of tile_world = 8 would each render it, one after the other on this GPU.  max_r T(r) against
+        # T(full) / 8 = load balance + fixed per-frame cost, everything but the gather itself.
+        def frame_ms(tile_rank, tile_world, out_ptr):
+            st = Hst.make_settings(w, h, spp=STRONG_SPP, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune,
+                                   tile_rank=tile_rank, tile_world=tile_world)
+            n = 10
+            ts = []
+            for rep in range(4):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    scene.render_device(st, out_ptr, stream=torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / n * 1e3)
+            return median(ts[1:])
+        t_full = frame_ms(0, 1, frame.data_ptr())
+        local, _g = D.alloc_tile_buffers(w, h, 8, dev)
+        t_rank = [frame_ms(r, 8, local.data_ptr()) for r in range(8)]
+        rank_share = {"tile_world": 8, "spp_total": STRONG_SPP, "t_full_ms": t_full, "t_rank_ms": t_rank,
+                      "rank_share_efficiency": (t_full / 8.0) / max(t_rank),
+                      "what": "T(full)/8 over max_r T(rank r of 8), each measured alone on this one GPU, host-timed with a "
+                              "device sync around 10 frames; excludes the RCCL gather (0.78 MB per rank)"}
+        # leave the work buffers sized for the bench frame again
+        st = Hst.make_settings(w, h, spp=spp0, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune, batch_spp=args.batch_spp)
+        scene.render_device(st, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        stats = scene.stats()
 
     if rank == 0:
-        value = rays_step * args.steps / dt / 1e6
+        prim_ms, prim_n = stats["primary_kernel_ms"], stats["primary_kernel_launches"]
+        bnc_ms, bnc_n = stats["bounce_kernel_ms"], stats["bounce_kernel_launches"]
+        spp = main_fig["spp_total"]
+        cfg2 = args.config == "cfg2"
         line = {
-            "metric": "Mrays/s (node) ufo.obj kd-tree 1080p", "value": value, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic camera rays over the reference's own assets (obj/ufo_fix.obj, cubemaps/blue_sunset)",
-            "config": {"workload": "BASELINE configs[1]: main.rs world (ufo_fix.obj rope kd-tree, 1705 tris, + 2 spheres), "
-                                   "blue_sunset cubemap, %dx%d, %d spp%s, max_bounce 2, reference ray semantics (prune_zero_mix=%d)"
-                                   % (W, H, spp, " (16 per GPU)" if world > 1 and args.scaling == "weak" else "", args.prune)
-                       if args.config == "cfg2" else "BASELINE %s; %d spp in total, max_bounce %d" % (what, spp, max_bounce),
-                       "rays_per_step": rays_step, "samples_per_step": paths_step,
-                       "msamples_per_s": paths_step * args.steps / dt / 1e6,
-                       "parallelism": "tiles%d" % world, "traversal_overflow": overflow},
+            "metric": "Mrays/s (node) ufo.obj kd-tree 1080p" if cfg2 else "Mrays/s (node) %s" % args.config,
+            "value": main_fig["value"], "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_fig["ms_per_step"],
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic camera rays over the reference's own assets (obj/ufo_fix.obj, cubemaps/blue_sunset)" if cfg2
+                    else "synthetic camera rays; scene of rustraytracer_amd/scenes.py:%s" % scene_fn,
+            "timing": main_fig["timing"],
+            "config": {"workload": ("BASELINE configs[1]: main.rs world (ufo_fix.obj rope kd-tree, 1705 tris, + 2 spheres), "
+                                    "blue_sunset cubemap, %dx%d, %d spp in total%s, max_bounce 2, reference ray semantics "
+                                    "(prune_zero_mix=%d)" % (w, h, spp, "" if world == 1 else
+                                                             (" (north_star's target frame, fixed as N grows)" if scaling == "strong"
+                                                              else " (16 per GPU)"), args.prune))
+                       if cfg2 else "BASELINE %s; %d spp in total, max_bounce %d" % (what, spp, max_bounce),
+                       "rays_per_step": main_fig["rays_per_step"], "samples_per_step": main_fig["samples_per_step"],
+                       "msamples_per_s": main_fig["samples_per_step"] / main_fig["ms_per_step"] / 1e3,
+                       "parallelism": "tiles%d" % world, "traversal_overflow": main_fig["traversal_overflow"],
+                       "n_batches": stats["n_batches"], "level_rays": stats["level_rays"]},
         }
+        if other is not None:
+            line["weak" if scaling == "strong" else "strong"] = {
+                "value": other["value"], "ms_per_step": other["ms_per_step"], "spp_total": other["spp_total"],
+                "rays_per_step": other["rays_per_step"], "timing": other["timing"]}
         if host_ms is not None:
             line["config"]["host_buffer_ms_per_step"] = host_ms      # rrt_render: + D2H of the RGB8 frame, blocking
-        cpu_c = prim_c = None
-        if args.config != "cfg2":
-            line["metric"] = "Mrays/s (node) %s" % args.config
-            line["config"]["n_batches"] = stats["n_batches"]
-            line["config"]["level_rays"] = stats["level_rays"]
-            line["config"]["kernel_ms"] = {"k_wave_primary": prim_ms, "k_wave_bounce": bnc_ms, "gpu": stats["gpu_ms"]}
-        if world == 1 and not args.no_cpu_baseline and args.config == "cfg2":
+        if rank_share is not None:
+            line["rank_share_efficiency"] = rank_share["rank_share_efficiency"]
+            line["rank_share"] = rank_share
+        if world == 1:
+            line["config"]["kernel_ms"] = {"k_wave_primary": prim_ms, "k_wave_bounce": bnc_ms, "gpu": stats["gpu_ms"],
+                                           "k_wave_primary_launches": prim_n, "k_wave_bounce_launches": bnc_n}
+        per = None
+        if world == 1 and not args.no_cpu_baseline and args.config in ("cfg2", "cfg5"):
             nthreads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-            line["cpu_baseline"], cpu_c, prim_c, n_prim = cpu_leg(nthreads)
-        if world == 1 and args.config == "cfg2":
-            # Dominant kernel = k_wave_primary (one launch per wavefront batch).  Its roofline is priced as
-            # DESIGN.md "Measurement" states: the scene of this config (~0.4 MB of nodes/triangles) is
-            # cache-resident, so the bytes that MUST cross HBM per primary ray are its outputs only:
-            #   path that ends in the sky: 3 B cubemap texel read + 4 B compact sample (the texel itself, samp32)
-            #   continuing path: 56 B shading record + 56 B queue entry (o, d, path, medium) + 4 B samp32 tag,
-            #                    + 24 B sample colour left in advance when its reflection ray has mix 0.0
-            # `achieved` = those bytes x rays per launch / measured launch time (hipEvents on the launch stream).
-            # The kernel is f64-VALU/latency bound; that ceiling is reported beside it as valu_f64.
+            line["cpu_baseline"], per = cpu_leg(args.config, nthreads, w, h, spp0, max_bounce)
+        if world == 1 and args.config in ("cfg2", "cfg5"):
+            # Dominant kernel = k_wave_primary (one launch per wavefront batch); live hipEvent timing on the launch stream.
             launch_ms = prim_ms / max(prim_n, 1)
             rays_per_launch = stats["primary_rays"] / max(prim_n, 1)
-            lv = stats["level_rays"]
-            cont = lv[1] / max(lv[0], 1)
-            dead = stats["zero_mix_paths"] / max(lv[0], 1)
-            hbm_bytes_ray = (1.0 - cont) * 7.0 + cont * 116.0 + dead * 24.0
-            ach = hbm_bytes_ray * rays_per_launch / (launch_ms * 1e-3) / 1e9
-            roof = {"kernel": "k_wave_primary", "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
-                    "achieved": ach, "frac": ach / PEAK_HBM_GBS, "traffic": None,
-                    "avg_launch_ms": launch_ms, "launches_per_step": prim_n, "rays_per_launch": rays_per_launch,
-                    "hbm_bytes_per_ray": hbm_bytes_ray, "continuing_fraction": cont, "zero_mix_fraction": dead,
+            io_b, cont, dead = io_bytes_per_ray(stats)
+            roof = {"kernel": "k_wave_primary", "avg_launch_ms": launch_ms, "launches_per_step": prim_n,
+                    "rays_per_launch": rays_per_launch, "continuing_fraction": cont, "zero_mix_fraction": dead,
                     "other_kernels": {"k_wave_bounce_ms_per_step": bnc_ms, "k_wave_bounce_launches": bnc_n,
-                                      "k_wave_primary_ms_per_step": prim_ms, "gpu_ms_per_step": stats["gpu_ms"],
-                                      "level_rays": lv}}
-            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tf):       # PMC FETCH_SIZE/WRITE_SIZE per launch, collected by tools/collect_pmc.sh
-                try:
-                    t = json.load(open(tf)).get("k_wave_primary")
-                    if t:
-                        roof["traffic"] = t["hbm_bytes_per_launch"]
-                        roof["traffic_source"] = t.get("source")
-                except (ValueError, KeyError):
-                    pass
-            vf = os.path.join(ROOT, "profiles", "valu_busy.json")
-            if os.path.exists(vf):       # SQ_ACTIVE_INST_VALU over the launch's SIMD-cycles (tools/valu_busy.py)
-                try:
-                    roof["valu_issue"] = json.load(open(vf)).get("k_wave_primary")
-                except ValueError:
-                    pass
-            if prim_c:
-                n = float(n_prim)
-                per = {k: prim_c[k] / n for k in ("node_steps", "leaf_visits", "tri_tests", "sphere_tests", "box_tests")}
-                onchip = per["node_steps"] * S_NODE + per["leaf_visits"] * S_LEAF + per["tri_tests"] * S_TRI
-                flops_ray = (per["tri_tests"] * F_TRI + per["box_tests"] * F_BOX + per["node_steps"] * F_NODE
-                             + per["sphere_tests"] * F_SPHERE + F_SHADE)
-                tf64 = flops_ray * rays_per_launch / (launch_ms * 1e-3) / 1e12
-                roof["valu_f64"] = {"achieved": tf64, "peak": PEAK_F64_TFLOPS, "frac": tf64 / PEAK_F64_TFLOPS,
-                                    "unit": "TFLOP/s", "flops_per_ray": flops_ray, "per_primary_ray": per,
-                                    "cache_served_bytes_per_ray": onchip,
-                                    "cache_served_GBs": onchip * rays_per_launch / (launch_ms * 1e-3) / 1e9}
+                                      "k_wave_primary_ms_per_step": prim_ms, "gpu_ms_per_step": stats["gpu_ms"]}}
+            traffic = attach_profiles(roof, args.config)
+            secs = launch_ms * 1e-3
+            if cfg2:
+                # SURVEY 8(d): cfg1-4 are NOT HBM-bound (the scene is cache/LDS resident): the bound is the f64 vector
+                # ALU.  achieved = the reference's flops per primary ray (oracle counters on the same tree) x rays / time.
+                hbm = io_b * rays_per_launch / secs / 1e9
+                roof.update({"bound": "valu_f64", "unit": "TFLOP/s", "peak": PEAK_F64_TFLOPS, "traffic": traffic})
+                if per:
+                    fl = flops_per_ray(per)
+                    ach = fl * rays_per_launch / secs / 1e12
+                    roof.update({"achieved": ach, "frac": ach / PEAK_F64_TFLOPS, "flops_per_ray": fl, "per_primary_ray": per,
+                                 "formula": "N_tri*53 + N_box*30 + N_node*1 + N_sphere*25 + 120 (BASELINE.md section 3)",
+                                 "note": "work delivered in the reference's flops (the cull skips most of the N_tri exact tests); "
+                                         "no-FMA ceiling of this path = peak/2; issue-side figure in `executed`"})
+                else:
+                    roof.update({"achieved": None, "frac": None})
+                roof["hbm"] = {"achieved": hbm, "peak": PEAK_HBM_GBS, "frac": hbm / PEAK_HBM_GBS, "unit": "GB/s",
+                               "bytes_per_ray": io_b, "algorithmic_bytes_per_launch": io_b * rays_per_launch, "traffic": traffic}
+            else:
+                roof.update({"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "traffic": traffic})
+                if per:
+                    tb = traversal_bytes_per_ray(per)
+                    ach = (io_b + tb) * rays_per_launch / secs / 1e9
+                    roof.update({"achieved": ach, "frac": ach / PEAK_HBM_GBS, "bytes_per_ray": io_b + tb,
+                                 "io_bytes_per_ray": io_b, "traversal_bytes_per_ray": tb, "per_primary_ray": per,
+                                 "algorithmic_bytes_per_launch": (io_b + tb) * rays_per_launch,
+                                 "formula": "B_io + N_node*16 + N_leaf*80 + N_tri*24 + N_tri_box_hit*72 + hit*28 (BASELINE.md section 3)"})
+                    fl = flops_per_ray(per)
+                    roof["valu_f64"] = {"achieved": fl * rays_per_launch / secs / 1e12, "peak": PEAK_F64_TFLOPS,
+                                        "frac": fl * rays_per_launch / secs / 1e12 / PEAK_F64_TFLOPS, "flops_per_ray": fl}
+                else:
+                    roof.update({"achieved": None, "frac": None})
             line["roofline"] = roof
         print(json.dumps(line), flush=True)
     if world > 1:

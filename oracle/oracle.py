@@ -77,6 +77,9 @@ def lib():
         L.orc_powi.argtypes = [C.c_double, C.c_int]
         L.orc_powi.restype = C.c_double
         L.orc_philox.argtypes = [C.c_void_p] * 3
+        L.orc_primary_rays_rows.argtypes = [C.POINTER(Camera), C.POINTER(Settings), C.c_void_p, C.c_int64, C.c_uint32, C.c_void_p]
+        L.orc_set_count_box_hits.argtypes = [C.c_int]
+        L.orc_set_static_chunks.argtypes = [C.c_int]
         L.orc_primary_ray.argtypes = [C.POINTER(Camera), C.POINTER(Settings), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         _LIB = L
     return _LIB
@@ -235,7 +238,7 @@ class OracleScene:
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
         n = rays.shape[0]
         out = dict(ent=np.zeros(n, np.int32), tri=np.zeros(n, np.int32), t=np.zeros(n),
-                   pos=np.zeros((n, 3)), normal=np.zeros((n, 3)), counters=np.zeros(7, np.uint64))
+                   pos=np.zeros((n, 3)), normal=np.zeros((n, 3)), counters=np.zeros(8, np.uint64))
         self.L.orc_trace_rays(self.h, _ptr(rays), n, _ptr(out["ent"]), _ptr(out["tri"]), _ptr(out["t"]),
                               _ptr(out["pos"]), _ptr(out["normal"]), _ptr(out["counters"]))
         return out
@@ -251,7 +254,7 @@ class OracleScene:
         cam = camera or default_camera()
         st = Settings(width, height, spp, max_bounce, seed, prune_zero_mix, n_threads)
         npx = width * height
-        out = dict(counters=np.zeros(7, np.uint64))
+        out = dict(counters=np.zeros(8, np.uint64))
         out["rgb"] = np.zeros((height, width, 3), np.uint8) if "rgb" in want else None
         out["ids"] = np.full((height, width, 2), -2, np.int32) if "ids" in want else None
         out["t"] = np.zeros((height, width)) if "t" in want else None
@@ -262,4 +265,4 @@ class OracleScene:
         return out
 
 
-COUNTER_NAMES = ["rays", "node_steps", "leaf_visits", "tri_tests", "sphere_tests", "box_tests", "overflow"]
+COUNTER_NAMES = ["rays", "node_steps", "leaf_visits", "tri_tests", "sphere_tests", "box_tests", "overflow", "tri_box_hits"]

@@ -136,13 +136,37 @@ struct AABB { V3 mn, mx; };
 
 struct Counters {
     uint64_t rays = 0, node_steps = 0, leaf_visits = 0, tri_tests = 0,
-             sphere_tests = 0, box_tests = 0, overflow = 0;
+             sphere_tests = 0, box_tests = 0, overflow = 0,
+             tri_box_hits = 0;   // bench instrumentation (g_count_box_hits): tested triangles whose own f64 box the ray crosses
     void add(const Counters& o) {
         rays += o.rays; node_steps += o.node_steps; leaf_visits += o.leaf_visits;
         tri_tests += o.tri_tests; sphere_tests += o.sphere_tests; box_tests += o.box_tests;
-        overflow += o.overflow;
+        overflow += o.overflow; tri_box_hits += o.tri_box_hits;
+    }
+    void store(uint64_t* out) const {   // 8 x u64, the order of oracle.py's COUNTER_NAMES
+        out[0] = rays; out[1] = node_steps; out[2] = leaf_visits; out[3] = tri_tests;
+        out[4] = sphere_tests; out[5] = box_tests; out[6] = overflow; out[7] = tri_box_hits;
     }
 };
+
+// Bench instrumentation only (never changes a result): does the half-line o + t d, t >= 0, cross the box?
+// Counts, per tested triangle, whether ANY box-based cull in front of triangle.rs:25-58 would have to let
+// it through -- the implementation-independent number of exact tests of the roofline's byte formula.
+bool g_count_box_hits = false;
+inline bool ray_crosses_box(const AABB& b, V3 o, V3 d) {
+    double lo = 0.0, hi = std::numeric_limits<double>::infinity();
+    for (int i = 0; i < 3; ++i) {
+        if (d[i] == 0.0) {
+            if (o[i] < b.mn[i] || o[i] > b.mx[i]) return false;
+            continue;
+        }
+        double t0 = (b.mn[i] - o[i]) / d[i], t1 = (b.mx[i] - o[i]) / d[i];
+        if (t0 > t1) std::swap(t0, t1);
+        if (t0 > lo) lo = t0;
+        if (t1 < hi) hi = t1;
+    }
+    return lo <= hi;
+}
 
 // aabb.rs:41-46
 inline bool contains(const AABB& b, V3 p) {
@@ -391,6 +415,7 @@ Collide kd_collide(const Mesh& m, const Ray& ray, Counters& c) {
         for (int id : leaf->leaf) {
             V3 pos; double t;
             ++c.tri_tests;
+            if (g_count_box_hits && ray_crosses_box(m.tri_box[id], ray.o, ray.d)) ++c.tri_box_hits;
             if (tri_collide(m.tris[id], ray.o, ray.d, &pos, &t)) {
                 const double dist = mag2(sub(pos, ray.o));
                 if (dist < min_d) {
@@ -860,10 +885,7 @@ void orc_trace_rays(void* h, const double* rays, int64_t n, int32_t* ent, int32_
         if (pos) { pos[3 * i] = hit.pos.x; pos[3 * i + 1] = hit.pos.y; pos[3 * i + 2] = hit.pos.z; }
         if (normal) { normal[3 * i] = hit.normal.x; normal[3 * i + 1] = hit.normal.y; normal[3 * i + 2] = hit.normal.z; }
     }
-    if (counters) {
-        counters[0] = c.rays; counters[1] = c.node_steps; counters[2] = c.leaf_visits; counters[3] = c.tri_tests;
-        counters[4] = c.sphere_tests; counters[5] = c.box_tests; counters[6] = c.overflow;
-    }
+    if (counters) c.store(counters);
 }
 
 // ---- full cast() for arbitrary rays -> colour (tracer.rs:177-211)
@@ -880,13 +902,14 @@ void orc_cast_rays(void* h, const double* rays, int64_t n, uint32_t max_bounce, 
 
 static bool g_static_chunks = false;
 void orc_set_static_chunks(int on) { g_static_chunks = on != 0; }
+void orc_set_count_box_hits(int on) { g_count_box_hits = on != 0; }
 
 // ---- render (tracer.rs:77-175, minus PNG save).  Rows y0 <= y < y1 with
 // (y - y0) % row_stride == 0 are rendered (the CPU-baseline leg times a bounded
 // strided sample; tests render everything).  Threads take rows from a shared
 // counter (the reference uses 12 static contiguous chunks, tracer.rs:117-158;
 // dynamic rows only change who computes a pixel, never its value).  All
-// outputs are full-frame row-major and may be null.  counters: 7 x u64.
+// outputs are full-frame row-major and may be null.  counters: 8 x u64.
 int orc_render(void* h, const Camera* cam, const Settings* stp, int64_t y0, int64_t y1, int64_t row_stride,
                uint8_t* out_rgb, int32_t* out_ids, double* out_t, double* out_color, uint64_t* counters) {
     Scene* s = (Scene*)h;
@@ -948,10 +971,7 @@ int orc_render(void* h, const Camera* cam, const Settings* stp, int64_t y0, int6
     for (auto& t : th) t.join();
     Counters c;
     for (auto& k : cs) c.add(k);
-    if (counters) {
-        counters[0] = c.rays; counters[1] = c.node_steps; counters[2] = c.leaf_visits; counters[3] = c.tri_tests;
-        counters[4] = c.sphere_tests; counters[5] = c.box_tests; counters[6] = c.overflow;
-    }
+    if (counters) c.store(counters);
     return 0;
 }
 
@@ -985,6 +1005,13 @@ void orc_primary_ray(const Camera* cam, const Settings* st, uint32_t x, uint32_t
     sample_jitter(*st, y * st->width + x, sample, &jx, &jy);
     Ray r = primary_ray(*cam, *st, x, y, jx, jy);
     out[0] = r.o.x; out[1] = r.o.y; out[2] = r.o.z; out[3] = r.d.x; out[4] = r.d.y; out[5] = r.d.z;
+}
+
+// sample `sample` primary rays of whole rows ys[0..n_rows): out = [n_rows][width][6]
+void orc_primary_rays_rows(const Camera* cam, const Settings* st, const int32_t* ys, int64_t n_rows, uint32_t sample, double* out) {
+    for (int64_t k = 0; k < n_rows; ++k)
+        for (uint32_t x = 0; x < st->width; ++x)
+            orc_primary_ray(cam, st, x, (uint32_t)ys[k], sample, out + 6 * ((size_t)k * st->width + x));
 }
 
 }  // extern "C"

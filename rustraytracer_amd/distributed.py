@@ -43,6 +43,43 @@ def gather_tiles(local, gathered):
     return gathered
 
 
+class TilePipeline:
+    """One frame per step() on this rank: render its tiles, all-gather, de-interleave -- with the
+    exchange of frame i overlapped with the render of frame i+1.  Renders run back to back on one
+    stream (they share the scene's work buffers, so they must not overlap each other); the gather
+    and the de-interleave of a frame run on a second stream behind an event; the tile buffers are
+    double-buffered so that render i+1 never writes what gather i still reads."""
+
+    def __init__(self, scene, width, height, world, device, frame):
+        from . import host as H
+        self._H = H
+        self.scene, self.w, self.h, self.world, self.frame = scene, width, height, world, frame
+        self.local, self.gathered = [], []
+        for _ in range(2):
+            lo, ga = alloc_tile_buffers(width, height, world, device)
+            self.local.append(lo)
+            self.gathered.append(ga)
+        self.s_render = torch.cuda.Stream(device=device)
+        self.s_comm = torch.cuda.Stream(device=device)
+        self.ev_render = [torch.cuda.Event(), torch.cuda.Event()]
+        self.ev_comm = [torch.cuda.Event(), torch.cuda.Event()]
+        self.i = 0
+
+    def step(self, settings):
+        k = self.i & 1
+        if self.i >= 2:
+            self.s_render.wait_event(self.ev_comm[k])        # frame i-2's gather has read local[k]
+        self.scene.render_device(settings, self.local[k].data_ptr(), stream=self.s_render.cuda_stream)
+        self.ev_render[k].record(self.s_render)
+        with torch.cuda.stream(self.s_comm):
+            self.s_comm.wait_event(self.ev_render[k])
+            gather_tiles(self.local[k], self.gathered[k])
+            self._H.assemble_tiles(self.gathered[k].data_ptr(), self.w, self.h, self.world, self.frame.data_ptr(),
+                                   stream=self.s_comm.cuda_stream)
+            self.ev_comm[k].record(self.s_comm)
+        self.i += 1
+
+
 def max_over_ranks(seconds, device):
     multi = dist.is_initialized() and dist.get_world_size() > 1
     t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if multi and _host_staged() else device)

@@ -1,20 +1,28 @@
 #!/bin/bash
-# Everything profiles/ holds for a round, in one GPU call (run from the repo root on the GPU box):
-#   bash tools/collect_all.sh r01
-# -> gpurun_out/<tag>_bench.json, <tag>_kernel_stats.csv, pmc_<tag>/, sq_<tag>/ ; copy into profiles/ afterwards
-# (tools/finish_profiles.sh does that here).
+# Everything profiles/ holds for a round and a config, in one GPU call (run from the repo root on the GPU box):
+#   bash tools/collect_all.sh r02            (cfg2, the bench workload)
+#   bash tools/collect_all.sh r02 cfg5       (any other --config: files get the suffix _cfg5)
+# -> gpurun_out/<tag><sfx>_bench.json, _kernel_stats.csv, _pmc_traffic.json, _sq_summary.txt, _tcp.txt + the raw trees;
+# tools/finish_profiles.sh copies them into profiles/ here.  Every GPU step has its own time limit and the
+# script stops at the first one that fails.
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
+CFG=${2:-cfg2}
+SFX=""; ARGS=""
+if [ "$CFG" != "cfg2" ]; then SFX="_$CFG"; ARGS="--config $CFG"; fi
 REPO=$PWD
 OUT=$REPO/gpurun_out
+T=$TAG$SFX
 mkdir -p $OUT
-timeout -k 10 400 python3 bench.py > $OUT/${TAG}_bench.json
+timeout -k 10 500 python3 bench.py $ARGS > $OUT/${T}_bench.json
 echo bench-done
-( cd /tmp && export TMPDIR=/tmp && timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_trace.log 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T}_trace -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --once $ARGS > $OUT/${T}_trace.log 2>&1 )
 echo trace-done
-bash tools/collect_pmc.sh $TAG
-bash tools/collect_sq.sh $TAG
-python3 tools/parse_pmc.py $OUT/pmc_$TAG > $OUT/${TAG}_pmc_traffic.json
-python3 tools/parse_sq.py $OUT/sq_$TAG > $OUT/${TAG}_sq_summary.txt
-find $OUT/${TAG}_trace -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
+bash tools/collect_pmc.sh $T $ARGS
+bash tools/collect_sq.sh $T $ARGS
+bash tools/tcp_cfg2.sh $T $ARGS
+python3 tools/parse_pmc.py $OUT/pmc_$T > $OUT/${T}_pmc_traffic.json
+python3 tools/parse_sq.py $OUT/sq_$T > $OUT/${T}_sq_summary.txt
+python3 tools/parse_counters.py $OUT/tcp_$T > $OUT/${T}_tcp.txt
+find $OUT/${T}_trace -name "*kernel_stats.csv" -exec cp {} $OUT/${T}_kernel_stats.csv \;
 echo all-done

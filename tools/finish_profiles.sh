@@ -1,15 +1,23 @@
 #!/bin/bash
-# Copies what tools/collect_all.sh produced (merged back under gpurun_out/) into profiles/.
+# Copies what tools/collect_all.sh produced (merged back under gpurun_out/) into profiles/:
+#   bash tools/finish_profiles.sh r02 [cfg5]
 set -e
-TAG=${1:-r01}
-cp gpurun_out/${TAG}_bench.json profiles/${TAG}_bench.json
-cp gpurun_out/${TAG}_kernel_stats.csv profiles/${TAG}_kernel_stats.csv
-cp gpurun_out/${TAG}_pmc_traffic.json profiles/pmc_traffic.json
-cp gpurun_out/${TAG}_sq_summary.txt profiles/${TAG}_sq_summary.txt
-python3 tools/valu_busy.py gpurun_out/sq_$TAG profiles/${TAG}_kernel_stats.csv > profiles/valu_busy.json
+TAG=${1:-r02}
+CFG=${2:-cfg2}
+SFX=""
+if [ "$CFG" != "cfg2" ]; then SFX="_$CFG"; fi
+T=$TAG$SFX
+mkdir -p profiles/counters
+cp gpurun_out/${T}_bench.json profiles/${T}_bench.json
+cp gpurun_out/${T}_kernel_stats.csv profiles/${T}_kernel_stats.csv
+cp gpurun_out/${T}_pmc_traffic.json profiles/pmc_traffic${SFX}.json
+cp gpurun_out/${T}_sq_summary.txt profiles/${T}_sq_summary.txt
+cp gpurun_out/${T}_tcp.txt profiles/counters/${T}_tcp.txt
+test -s profiles/counters/${T}_tcp.txt || { echo "empty TCP summary"; exit 1; }
+python3 tools/valu_busy.py gpurun_out/sq_$T profiles/${T}_kernel_stats.csv > profiles/valu_busy${SFX}.json
 for C in FETCH_SIZE WRITE_SIZE; do
-  f=$(find gpurun_out/pmc_$TAG/$C -name "*counter_collection.csv" | head -1)
-  python3 - "$f" profiles/${TAG}_pmc_$C.csv <<'PY'
+  f=$(find gpurun_out/pmc_$T/$C -name "*counter_collection.csv" | head -1)
+  python3 - "$f" profiles/${T}_pmc_$C.csv <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_" in r["Kernel_Name"]]
 keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value"]
@@ -18,19 +26,23 @@ w = csv.DictWriter(open(sys.argv[2], "w"), keep); w.writeheader()
 for r in rows: w.writerow({k: r[k] for k in keep})
 PY
 done
-# bench.py attaches profiles/pmc_traffic.json and profiles/valu_busy.json as it finds them at run time, i.e. the
+# bench.py attaches profiles/pmc_traffic*.json and profiles/valu_busy*.json as it finds them at run time, i.e. the
 # PREVIOUS collection's; re-attach the ones this collection produced so the committed line is self-consistent.
-python3 - profiles/${TAG}_bench.json <<'PY'
+python3 - profiles/${T}_bench.json "$SFX" <<'PY'
 import json, sys
-f = sys.argv[1]
+f, sfx = sys.argv[1], sys.argv[2]
 d = json.load(open(f))
-t = json.load(open("profiles/pmc_traffic.json")).get("k_wave_primary")
-v = json.load(open("profiles/valu_busy.json")).get("k_wave_primary")
+t = json.load(open("profiles/pmc_traffic%s.json" % sfx)).get("k_wave_primary")
+v = json.load(open("profiles/valu_busy%s.json" % sfx)).get("k_wave_primary")
+r = d["roofline"]
 if t:
-    d["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-    d["roofline"]["traffic_source"] = t.get("source")
+    r["traffic"] = t["hbm_bytes_per_launch"]
+    if "hbm" in r: r["hbm"]["traffic"] = t["hbm_bytes_per_launch"]
+    r["traffic_source"] = "profiles/pmc_traffic%s.json: %s" % (sfx, t.get("source"))
 if v:
-    d["roofline"]["valu_issue"] = v
+    r["executed"] = {"valu_busy": v["valu_busy"], "lane_utilisation": v["lane_utilisation"],
+                     "issue_slot_frac": v["valu_busy"] * (v["lane_utilisation"] or 0.0), "waves_per_simd": v["waves_per_simd"],
+                     "avg_launch_ns": v["avg_launch_ns"], "source": "profiles/valu_busy%s.json: %s" % (sfx, v.get("source"))}
 json.dump(d, open(f, "w"))
 PY
 ls -la profiles
