@@ -81,6 +81,11 @@ extern "C" {
     pub fn rrt_set_sky_face(s: *mut rrt_scene, face: c_int, rgb8: *const u8, w: u32, h: u32) -> c_int;
     pub fn rrt_set_directional_light(s: *mut rrt_scene, direction: *const f64, color: *const f64,
                                      intensity: f64) -> c_int;
+    pub fn rrt_add_point_light(s: *mut rrt_scene, position: *const f64, color: *const f64, brightness: f64,
+                               attenuation: f64) -> c_int;
+    pub fn rrt_set_shadow_mode(s: *mut rrt_scene, mode: c_int) -> c_int;
+    pub fn rrt_translate_entity(s: *mut rrt_scene, entity: c_int, delta: *const f64, refit: c_int) -> c_int;
+    pub fn rrt_occluded_rays(s: *mut rrt_scene, rays: *const f64, max_dist2: *const f64, n: i64, out: *mut u8) -> c_int;
     pub fn rrt_set_ambient(s: *mut rrt_scene, ambient: f64) -> c_int;
     pub fn rrt_set_work_budget(s: *mut rrt_scene, bytes: u64) -> c_int;
     pub fn rrt_set_cull_mode(s: *mut rrt_scene, mode: c_int) -> c_int;

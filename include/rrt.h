@@ -173,6 +173,41 @@ int rrt_set_directional_light(rrt_scene* s, const double direction[3], const dou
 
 int rrt_set_ambient(rrt_scene* s, double ambient);             /* World.ambient, tracer.rs:73 */
 
+/* PointLight{position, color, brightness, attenuation} pushed to world.light_sources
+ * (src/lighting.rs:52-89).  The reference gives the struct no constructor and main.rs never builds
+ * one (dead code there), so this is PARITY UNPINNED against the reference and
+ * restated from the impl block alone: illuminate = {power: brightness / (attenuation * |pos-light|^2),
+ * direction: normalize(pos - light)} (lighting.rs:60-68), summed by Lambert and Phong after the
+ * directional light, in push order (lambert.rs:34-43, phong.rs:37-45).  At most 16.  Its visible()
+ * casts a SHADOW RAY through the world -- an any-hit walk of the same entities / kd-trees (the
+ * first accepted triangle that is close enough ends it) -- see rrt_set_shadow_mode.
+ * Returns the light's index. */
+int rrt_add_point_light(rrt_scene* s, const double position[3], const double color[3], double brightness,
+                        double attenuation);
+
+/* How PointLight::visible is answered.
+ *   0 (default) = src/lighting.rs:70-84 exactly as written: the ray starts ON the surface, its
+ *       direction (light - pos) is not normalised, and the loop answers "visible" as soon as ONE
+ *       entity of the world is missed, "not visible" only when every entity is hit (inverted with
+ *       respect to a shadow test; an empty world is never lit).  Restated because it is the code.
+ *   1 = EXTENSION, the corrected test: the surface must face the light (n . (pos - light) < 0, as
+ *       DirectionalLight::visible lighting.rs:43-45), the ray starts at pos + normal*0.3 (the offset
+ *       reflection.rs:30 uses) with a normalised direction, and the light is visible iff no entity
+ *       answers Entity::collide closer than the light. */
+int rrt_set_shadow_mode(rrt_scene* s, int mode);
+
+/* Entity::translate(vec) (src/geometry/sphere.rs:68-70; model.rs:80-86 = Triangle::translate
+ * triangle.rs:79-83 on every triangle + KDTree::translate_nodes kdtree.rs:35-42; scene.rs:68-74 =
+ * every member + the group's own nodes).  Never called by the reference's render.
+ *   refit = 0: as written -- vertices and split planes move, the nodes' boxes (and the model's
+ *       aa_bb) stay where they were, because translate_nodes forgets them: rays are then walked
+ *       through the stale boxes, bit for bit as the Rust code would.
+ *   refit = 1: EXTENSION -- every box of the tree moves as well (AABB::translate aabb.rs:116-119 on
+ *       each node), i.e. a rigid translation: the result equals a scene built at the new place
+ *       whenever the additions are exact.
+ * The scene is re-uploaded by the next render / rrt_scene_commit. */
+int rrt_translate_entity(rrt_scene* s, int entity, const double delta[3], int refit);
+
 /* Upper bound in bytes for per-render wavefront work buffers (queues, path
  * records, sample buffer).  Default 16 GiB. */
 int rrt_set_work_budget(rrt_scene* s, uint64_t bytes);
@@ -236,6 +271,13 @@ int rrt_assemble_tiles(const void* d_gathered, uint32_t width, uint32_t height, 
  * may be NULL.  ent -1 = miss. */
 int rrt_trace_rays(rrt_scene* s, const double* rays, int64_t n, int32_t* ent, int32_t* tri, double* t, double* pos,
                    double* normal);
+
+/* The shadow-ray question for caller supplied rays (the loop of PointLight::visible,
+ * src/lighting.rs:77-82, in its corrected sense): out[i] = 1 iff some entity of world.entities
+ * answers Entity::collide for ray i with a position closer to the origin than max_dist2[i]
+ * (squared; pass DBL_MAX for "any hit").  An any-hit walk: entities in order, each kd-tree left at
+ * the first accepted triangle that is close enough.  Host pointers. */
+int rrt_occluded_rays(rrt_scene* s, const double* rays, const double* max_dist2, int64_t n, uint8_t* out);
 
 /* RayTracer::cast (src/tracer.rs:177-211) for caller supplied bounce-0 rays:
  * full shading incl. reflection chain; color: 3 doubles per ray. */

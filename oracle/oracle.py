@@ -64,6 +64,10 @@ def lib():
         L.orc_set_sky_face.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]
         L.orc_set_directional_light.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]
         L.orc_set_ambient.argtypes = [C.c_void_p, C.c_double]
+        L.orc_add_point_light.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double]
+        L.orc_set_shadow_mode.argtypes = [C.c_void_p, C.c_int]
+        L.orc_translate_entity.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]
+        L.orc_occluded_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.orc_mesh_tree_sizes.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_mesh_tree_export.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
         L.orc_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 6
@@ -222,6 +226,29 @@ class OracleScene:
 
     def set_ambient(self, a):
         self.L.orc_set_ambient(self.h, float(a))
+
+    def add_point_light(self, position, color, brightness, attenuation):
+        """PointLight{position, color, brightness, attenuation} (lighting.rs:52-57) pushed to world.light_sources."""
+        i = self.L.orc_add_point_light(self.h, _d3(position), _d3(color), float(brightness), float(attenuation))
+        if i < 0:
+            raise ValueError("too many point lights")
+        return i
+
+    def set_shadow_mode(self, mode):
+        self.L.orc_set_shadow_mode(self.h, int(mode))
+
+    def translate(self, ent, vec, refit=0):
+        """Entity::translate (sphere.rs:68-70, model.rs:80-86, scene.rs:68-74); refit = the extension that
+        also moves the boxes the reference leaves behind."""
+        if self.L.orc_translate_entity(self.h, int(ent), _d3(vec), int(refit)) != 0:
+            raise ValueError("unknown entity")
+
+    def occluded_rays(self, rays, lim2):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        lim2 = np.ascontiguousarray(np.broadcast_to(np.asarray(lim2, dtype=np.float64), (rays.shape[0],)))
+        out = np.zeros(rays.shape[0], np.uint8)
+        self.L.orc_occluded_rays(self.h, _ptr(rays), _ptr(lim2), rays.shape[0], _ptr(out))
+        return out
 
     def tree(self, ent):
         nn, nr = C.c_int(), C.c_int()

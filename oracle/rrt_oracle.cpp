@@ -503,6 +503,12 @@ struct Scene {
     bool has_light = false;
     V3 light_dir{0, 0, 0}, light_color{0, 0, 0}; double light_intensity = 0;
     double ambient = 0.15;
+    // lighting.rs:52-57.  The reference gives PointLight no constructor (private fields, never built by
+    // main.rs): PARITY UNPINNED -- restated from the impl block alone.  world.light_sources order here:
+    // the directional light first (new_empty_world pushes it, tracer.rs:55-65), then these in push order.
+    struct PointLight { V3 pos, color; double brightness, attenuation; };
+    std::vector<PointLight> point_lights;
+    int shadow_mode = 0;   // 0 = PointLight::visible exactly as written (lighting.rs:70-84); 1 = corrected (extension)
 };
 
 struct Camera { double eye[3]; double lens_z; double lens_w, lens_h; };
@@ -665,6 +671,51 @@ inline Ray continuation(const Settings& st, const Material& m, const Ray& ray, c
     return out;
 }
 
+// Entity::collide of a top-level entity (a sphere, a mesh or a Scene<T> group), any kind.
+inline Collide top_level_collide(const Scene& sc, size_t e, const Ray& ray, Counters& c) {
+    int who;
+    if (sc.ents[e].kind == 2) return group_collide(sc, *sc.groups[sc.ents[e].index], ray, &who, c);
+    return entity_collide(sc, (int)e, ray, c);
+}
+
+// The any-hit question a shadow ray asks: does some entity of world.entities answer the ray with a
+// collision whose position is closer to the origin than lim2 (squared)?  Defined through
+// Entity::collide itself (closest hit of the first kd leaf in which anything is hit, Q5), so that an
+// implementation may stop at the first accepted triangle that is close enough and still agree.
+inline bool occluded(const Scene& sc, const Ray& ray, double lim2, Counters& c) {
+    for (size_t e = 0; e < sc.ents.size(); ++e) {
+        if (sc.ents[e].parent >= 0) continue;
+        const Collide r = top_level_collide(sc, e, ray, c);
+        if (r.hit && mag2(sub(r.pos, ray.o)) < lim2) return true;
+    }
+    return false;
+}
+
+// PointLight::visible.
+//  mode 0: lighting.rs:70-84 as written -- the shadow ray starts ON the surface, its direction
+//          (light - pos) is NOT normalised, and the loop answers "visible" as soon as ONE entity is
+//          missed, "not visible" only if every entity of the world is hit (an empty world: not
+//          visible).  That is inverted with respect to what a shadow test means; it is restated
+//          because it is what the reference's code says.
+//  mode 1: EXTENSION, the corrected test: the surface must face the light (as DirectionalLight::visible,
+//          lighting.rs:43-45), the ray starts at pos + normal*0.3 (the offset reflection.rs:30 uses),
+//          is normalised, and the light is visible iff nothing is hit closer than the light.
+inline bool point_light_visible(const Scene& sc, const Scene::PointLight& L, V3 pos, V3 normal, Counters& c) {
+    if (sc.shadow_mode == 0) {
+        Ray r; r.o = pos; r.d = sub(L.pos, pos); r.bounce = 0;
+        for (size_t e = 0; e < sc.ents.size(); ++e) {
+            if (sc.ents[e].parent >= 0) continue;
+            if (!top_level_collide(sc, e, r, c).hit) return true;
+        }
+        return false;
+    }
+    if (!(dot(normal, sub(pos, L.pos)) < 0.)) return false;
+    Ray r; r.o = add(pos, mul(normal, 0.3)); r.bounce = 0;
+    const V3 v = sub(L.pos, r.o);
+    r.d = normalize(v);
+    return !occluded(sc, r, mag2(v), c);
+}
+
 V3 cast(const Scene& sc, const Settings& st, const Ray& ray, Counters& c, Primary* prim, uint32_t pixel = 0,
         uint32_t sample = 0) {
     ++c.rays;
@@ -675,11 +726,26 @@ V3 cast(const Scene& sc, const Settings& st, const Ray& ray, Counters& c, Primar
         const Material& m = sc.mats[hit.mat];
         V3 final_color = mul(m.color, sc.ambient);
         const bool visible = sc.has_light && (dot(hit.normal, sc.light_dir) < 0.);  // lighting.rs:43-45
+        // visible() of each point light: asked by Lambert and again by Phong (lambert.rs:35, phong.rs:38)
+        // with the same arguments, so evaluated once
+        bool pl_visible[16];
+        for (size_t k = 0; k < sc.point_lights.size(); ++k)
+            pl_visible[k] = point_light_visible(sc, sc.point_lights[k], hit.pos, hit.normal, c);
         // shaders[0] = Lambert
         {
             V3 result{0., 0., 0.};
             if (visible) {
                 double power = sc.light_intensity * (m.albedo / 3.14159265358979323846) * -dot(hit.normal, sc.light_dir);
+                power = std::fmax(power, 0.);
+                result = add(result, mul(m.color, power));
+            }
+            for (size_t k = 0; k < sc.point_lights.size(); ++k) {       // the other light_sources, lambert.rs:34-43
+                if (!pl_visible[k]) continue;
+                const Scene::PointLight& L = sc.point_lights[k];
+                const V3 dir0 = sub(hit.pos, L.pos);                      // lighting.rs:61-67
+                const double distance2 = mag2(dir0);
+                const V3 dir = normalize(dir0);
+                double power = (L.brightness / (L.attenuation * distance2)) * (m.albedo / 3.14159265358979323846) * -dot(hit.normal, dir);
                 power = std::fmax(power, 0.);
                 result = add(result, mul(m.color, power));
             }
@@ -698,6 +764,16 @@ V3 cast(const Scene& sc, const Settings& st, const Ray& ray, Counters& c, Primar
                 const V3 bis = normalize(sub(neg(sc.light_dir), ray.d));
                 const double power = sc.light_intensity * powi(std::fmax(dot(bis, hit.normal), 0.), m.alpha);
                 result = add(result, mul(sc.light_color, power));
+            }
+            for (size_t k = 0; k < sc.point_lights.size(); ++k) {       // phong.rs:37-45
+                if (!pl_visible[k]) continue;
+                const Scene::PointLight& L = sc.point_lights[k];
+                const V3 dir0 = sub(hit.pos, L.pos);
+                const double distance2 = mag2(dir0);
+                const V3 dir = normalize(dir0);
+                const V3 bis = normalize(sub(neg(dir), ray.d));
+                const double power = (L.brightness / (L.attenuation * distance2)) * powi(std::fmax(dot(bis, hit.normal), 0.), m.alpha);
+                result = add(result, mul(L.color, power));
             }
             final_color = add(final_color, mul(result, m.mixP));
         }
@@ -834,6 +910,64 @@ void orc_set_directional_light(void* h, const double dir[3], const double color[
     s->light_intensity = intensity;
 }
 void orc_set_ambient(void* h, double a) { ((Scene*)h)->ambient = a; }
+
+// PointLight{position, color, brightness, attenuation} (lighting.rs:52-57); at most 16.
+int orc_add_point_light(void* h, const double pos[3], const double color[3], double brightness, double attenuation) {
+    Scene* s = (Scene*)h;
+    if (s->point_lights.size() >= 16) return -1;
+    s->point_lights.push_back(Scene::PointLight{V3{pos[0], pos[1], pos[2]}, V3{color[0], color[1], color[2]}, brightness, attenuation});
+    return (int)s->point_lights.size() - 1;
+}
+void orc_set_shadow_mode(void* h, int mode) { ((Scene*)h)->shadow_mode = mode; }
+
+// Entity::translate (sphere.rs:68-70; model.rs:80-86 = Triangle::translate triangle.rs:79-83 on every
+// triangle + KDTree::translate_nodes kdtree.rs:35-42; scene.rs:68-74 = every member + the group's nodes).
+// translate_nodes moves the split planes only: the nodes' boxes, the model's aa_bb and its `position`
+// stay where they were (the reference forgets them) -- restated as written when refit == 0.
+// refit != 0 (EXTENSION): every box of the tree moves too (AABB::translate, aabb.rs:116-119, applied to
+// each node), which is what a rigid translation of the whole structure means.
+static void translate_nodes(KdNode* n, V3 v, bool refit) {
+    if (refit) { n->box.mn = add(n->box.mn, v); n->box.mx = add(n->box.mx, v); }
+    if (n->axis >= 0) {
+        n->partition += v[n->axis];
+        translate_nodes(n->left.get(), v, refit);
+        translate_nodes(n->right.get(), v, refit);
+    }
+}
+static void translate_entity(Scene* s, int e, V3 v, bool refit) {
+    const Entity ent = s->ents[e];
+    if (ent.kind == 0) {
+        s->spheres[ent.index].c = add(s->spheres[ent.index].c, v);
+    } else if (ent.kind == 1) {
+        Mesh& m = *s->meshes[ent.index];
+        for (size_t i = 0; i < m.tris.size(); ++i) {
+            Triangle& t = m.tris[i];
+            t.v0 = add(t.v0, v); t.v1 = add(t.v1, v); t.v2 = add(t.v2, v);
+            m.tri_box[i] = t.bbox();        // instrumentation only (tri_box_hits); the tree does not read it again
+        }
+        translate_nodes(m.root.get(), v, refit);
+    } else {
+        Group& g = *s->groups[ent.index];
+        for (int mem : g.members) translate_entity(s, mem, v, refit);
+        translate_nodes(g.root.get(), v, refit);
+    }
+}
+int orc_translate_entity(void* h, int e, const double v[3], int refit) {
+    Scene* s = (Scene*)h;
+    if (e < 0 || e >= (int)s->ents.size()) return -1;
+    translate_entity(s, e, V3{v[0], v[1], v[2]}, refit != 0);
+    return 0;
+}
+
+// any-hit query for caller rays: out[i] = 1 iff some entity answers ray i closer than lim2[i] (squared distance)
+void orc_occluded_rays(void* h, const double* rays, const double* lim2, int64_t n, uint8_t* out) {
+    Scene* s = (Scene*)h;
+    Counters c;
+    for (int64_t i = 0; i < n; ++i) {
+        Ray r{V3{rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]}, V3{rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]}, 0};
+        out[i] = occluded(*s, r, lim2[i], c) ? 1 : 0;
+    }
+}
 
 // ---- flattened-tree export (pre-order), for comparison with the product's builder
 // (a mesh's tree over its triangles, or a group's tree over its members)

@@ -41,7 +41,8 @@ EXPORTS = [
     "rrt_last_error", "rrt_version", "rrt_set_device", "rrt_device_image_support",
     "rrt_default_camera", "rrt_default_settings", "rrt_scene_create", "rrt_scene_destroy",
     "rrt_add_material", "rrt_add_material_ext", "rrt_add_sphere", "rrt_add_mesh", "rrt_add_group", "rrt_set_sky_face",
-    "rrt_set_directional_light", "rrt_set_ambient", "rrt_set_work_budget", "rrt_set_cull_mode",
+    "rrt_set_directional_light", "rrt_set_ambient", "rrt_add_point_light", "rrt_set_shadow_mode", "rrt_translate_entity",
+    "rrt_occluded_rays", "rrt_set_work_budget", "rrt_set_cull_mode",
     "rrt_scene_commit",
     "rrt_render", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_assemble_tiles",
     "rrt_trace_rays", "rrt_cast_rays", "rrt_get_stats", "rrt_mesh_tree_sizes",
@@ -86,6 +87,10 @@ def _load():
     L.rrt_set_sky_face.argtypes = [vp, i32, vp, u32, u32]
     L.rrt_set_directional_light.argtypes = [vp, dp, dp, C.c_double]
     L.rrt_set_ambient.argtypes = [vp, C.c_double]
+    L.rrt_add_point_light.argtypes = [vp, dp, dp, C.c_double, C.c_double]
+    L.rrt_set_shadow_mode.argtypes = [vp, i32]
+    L.rrt_translate_entity.argtypes = [vp, i32, dp, i32]
+    L.rrt_occluded_rays.argtypes = [vp, vp, vp, i64, vp]
     L.rrt_set_work_budget.argtypes = [vp, u64]
     L.rrt_set_cull_mode.argtypes = [vp, i32]
     L.rrt_scene_commit.argtypes = [vp]

@@ -71,10 +71,12 @@ struct DevBuf {
 };
 
 struct HostMesh {
+    std::vector<double> verts;       // 9 per triangle (v0, v1, v2): Triangle::translate moves these, the edges follow
     std::vector<rrt::DTri> tris;
     std::vector<double> normals;
     rrt::KdTreeFlat tree;
     int material = 0;
+    bool stale_boxes = false;        // went through a literal translate: the boxes no longer match the split planes
     // device copies
     DevBuf d_nodes, d_boxes, d_leaves, d_refs, d_tris, d_normals, d_cull, d_grp;
 };
@@ -83,6 +85,7 @@ struct HostMesh {
 struct HostGroup {
     std::vector<int32_t> members;   // entity ids, in the order given (= item numbers of the tree)
     rrt::KdTreeFlat tree;
+    bool stale_boxes = false;
     DevBuf d_nodes, d_boxes, d_leaves, d_members;
 };
 
@@ -112,6 +115,8 @@ struct rrt_scene {
     std::vector<std::unique_ptr<HostGroup>> groups;
     std::vector<double> sphere_radius;   // Sphere::bounding_box needs r, the kernels only r^2
     std::vector<rrt::DEntity> ents;
+    std::vector<rrt::DPointLight> plights;   // world.light_sources behind the directional light
+    int shadow_mode = 0;
     SkyFace sky[6];
     bool has_light = false;
     double light_dir[3] = {0, 0, 0}, light_color[3] = {0, 0, 0}, light_intensity = 0.0;
@@ -120,7 +125,7 @@ struct rrt_scene {
     int cull_mode = 1;
 
     bool dirty = true;
-    DevBuf d_ents, d_spheres, d_meshes, d_mats, d_groups;
+    DevBuf d_ents, d_spheres, d_meshes, d_mats, d_groups, d_plights;
     rrt::DScene dscene{};
 
     // work buffers
@@ -218,12 +223,17 @@ int commit(rrt_scene* s) {
         // outward-rounded f32 boxes of the stream entries + the cull constants
         std::vector<rrt::DBox32> cull(stream.size());
         double edge_max = 0.0;
+        // bounds of the triangles themselves: the cull's distance bound must hold for where the triangles ARE,
+        // which after a literal rrt_translate_entity is no longer the tree's (stale) root box
+        double tmn[3] = {INFINITY, INFINITY, INFINITY}, tmx[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (size_t j = 0; j < stream.size(); ++j) {
             const rrt::DTri& t = stream[j];
             double l1 = 0.0, l2 = 0.0;
             for (int a = 0; a < 3; ++a) {
                 const double p0 = t.v0[a], p1 = t.v0[a] + t.e1[a], p2 = t.v0[a] + t.e2[a];
                 const double lo = std::fmin(p0, std::fmin(p1, p2)), hi = std::fmax(p0, std::fmax(p1, p2));
+                tmn[a] = std::fmin(tmn[a], lo);
+                tmx[a] = std::fmax(tmx[a], hi);
                 float flo = (float)lo, fhi = (float)hi;
                 if ((double)flo > lo) flo = std::nextafterf(flo, -INFINITY);
                 if ((double)fhi < hi) fhi = std::nextafterf(fhi, INFINITY);
@@ -254,7 +264,8 @@ int commit(rrt_scene* s) {
         {
             double r2 = 0.0, am = 0.0;
             for (int a = 0; a < 3; ++a) {
-                const double lo = T.boxes[a], hi = T.boxes[3 + a];
+                // (one ulp of slack per bound: p0 + e is the rounded sum, not the stored vertex)
+                const double lo = std::nextafter(std::fmin(tmn[a], T.boxes[a]), -INFINITY), hi = std::nextafter(std::fmax(tmx[a], T.boxes[3 + a]), INFINITY);
                 dm[i].center[a] = 0.5 * (lo + hi);
                 r2 += 0.25 * (hi - lo) * (hi - lo);
                 am = std::fmax(am, std::fmax(std::fabs(lo), std::fabs(hi)));
@@ -270,7 +281,7 @@ int commit(rrt_scene* s) {
         dm[i].tris = m.d_tris.as<rrt::DTri>();
         dm[i].normals = m.d_normals.as<double>();
         dm[i].material = m.material;
-        dm[i].n_nodes = T.n_nodes();
+        dm[i].flags = m.stale_boxes ? rrt::kTreeStaleBoxes : 0;
     }
     HIP_TRY(s->d_meshes.upload(dm.data(), dm.size() * sizeof(rrt::DMesh)));
     std::vector<rrt::DGroup> dg(s->groups.size());
@@ -316,12 +327,17 @@ int commit(rrt_scene* s) {
         dg[i].boxes = g.d_boxes.as<rrt::DBox>();
         dg[i].leaves = g.d_leaves.as<rrt::DLeaf>();
         dg[i].members = g.d_members.as<int32_t>();
+        dg[i].flags = g.stale_boxes ? rrt::kTreeStaleBoxes : 0;
     }
     HIP_TRY(s->d_groups.upload(dg.data(), dg.size() * sizeof(rrt::DGroup)));
     HIP_TRY(s->d_spheres.upload(s->spheres.data(), s->spheres.size() * sizeof(rrt::DSphere)));
     HIP_TRY(s->d_mats.upload(s->mats.data(), s->mats.size() * sizeof(rrt::DMaterial)));
     HIP_TRY(s->d_ents.upload(s->ents.data(), s->ents.size() * sizeof(rrt::DEntity)));
+    HIP_TRY(s->d_plights.upload(s->plights.data(), s->plights.size() * sizeof(rrt::DPointLight)));
     rrt::DScene& d = s->dscene;
+    d.plights = s->d_plights.as<rrt::DPointLight>();
+    d.n_plights = (int32_t)s->plights.size();
+    d.shadow_mode = s->shadow_mode;
     d.ents = s->d_ents.as<rrt::DEntity>();
     d.spheres = s->d_spheres.as<rrt::DSphere>();
     d.meshes = s->d_meshes.as<rrt::DMesh>();
@@ -698,6 +714,7 @@ int rrt_add_mesh(rrt_scene* s, const double* verts, const double* normals, int64
             t.e2[a] = v[6 + a] - v[a];  // triangle.rs:31
         }
     }
+    m->verts.assign(verts, verts + 9 * n);
     m->normals.assign(normals, normals + 3 * n);
     m->tree = rrt::build_kd_tree(verts, n);
     s->meshes.push_back(std::move(m));
@@ -771,6 +788,81 @@ int rrt_set_directional_light(rrt_scene* s, const double direction[3], const dou
     s->has_light = true;
     s->dirty = true;
     return RRT_OK;
+}
+
+int rrt_add_point_light(rrt_scene* s, const double position[3], const double color[3], double brightness,
+                        double attenuation) try {
+    if (!s || !position || !color) return fail(RRT_E_INVALID, "null argument");
+    if (s->plights.size() >= (size_t)rrt::kMaxPointLights) return fail(RRT_E_INVALID, "too many point lights (<= 16)");
+    rrt::DPointLight L{};
+    for (int a = 0; a < 3; ++a) {
+        L.pos[a] = position[a];
+        L.color[a] = color[a];
+    }
+    L.brightness = brightness;
+    L.attenuation = attenuation;
+    s->plights.push_back(L);
+    s->dirty = true;
+    return (int)s->plights.size() - 1;
+} catch (...) {
+    return on_exception();
+}
+
+int rrt_set_shadow_mode(rrt_scene* s, int mode) {
+    if (!s || mode < 0 || mode > 1) return fail(RRT_E_INVALID, "shadow mode must be 0 (as the reference wrote it) or 1 (corrected)");
+    s->shadow_mode = mode;
+    s->dirty = true;
+    return RRT_OK;
+}
+
+namespace {
+// KDTree::translate_nodes (kdtree.rs:35-42): split planes move; boxes only with the refit extension.
+void translate_tree(rrt::KdTreeFlat& T, const double v[3], bool refit) {
+    for (size_t k = 0; k < T.axis.size(); ++k) {
+        if (T.axis[k] >= 0) T.split[k] += v[T.axis[k]];
+        if (refit)
+            for (int a = 0; a < 3; ++a) {
+                T.boxes[6 * k + a] += v[a];
+                T.boxes[6 * k + 3 + a] += v[a];
+            }
+    }
+}
+void translate_entity(rrt_scene* s, int e, const double v[3], bool refit) {
+    const rrt::DEntity ent = s->ents[(size_t)e];
+    const int kind = ent.kind & ~rrt::kEntityMember;
+    if (kind == 0) {                                   // sphere.rs:68-70
+        for (int a = 0; a < 3; ++a) s->spheres[(size_t)ent.index].c[a] += v[a];
+    } else if (kind == 1) {                            // model.rs:80-86 -> triangle.rs:79-83 + translate_nodes
+        HostMesh& m = *s->meshes[(size_t)ent.index];
+        for (size_t i = 0; i < m.tris.size(); ++i) {
+            double* p = &m.verts[9 * i];
+            for (int k = 0; k < 9; ++k) p[k] += v[k % 3];
+            rrt::DTri& t = m.tris[i];
+            for (int a = 0; a < 3; ++a) {
+                t.v0[a] = p[a];
+                t.e1[a] = p[3 + a] - p[a];             // triangle.rs:30-31 on the moved vertices
+                t.e2[a] = p[6 + a] - p[a];
+            }
+        }
+        translate_tree(m.tree, v, refit);
+        if (!refit) m.stale_boxes = true;
+    } else {                                           // scene.rs:68-74
+        HostGroup& g = *s->groups[(size_t)ent.index];
+        for (int32_t mem : g.members) translate_entity(s, mem, v, refit);
+        translate_tree(g.tree, v, refit);
+        if (!refit) g.stale_boxes = true;
+    }
+}
+}  // namespace
+
+int rrt_translate_entity(rrt_scene* s, int entity, const double delta[3], int refit) try {
+    if (!s || !delta) return fail(RRT_E_INVALID, "null argument");
+    if (entity < 0 || entity >= (int)s->ents.size()) return fail(RRT_E_INVALID, "unknown entity id");
+    translate_entity(s, entity, delta, refit != 0);
+    s->dirty = true;
+    return RRT_OK;
+} catch (...) {
+    return on_exception();
 }
 
 int rrt_set_ambient(rrt_scene* s, double ambient) {
@@ -868,8 +960,8 @@ static int ray_query(rrt_scene* s, const double* rays, int64_t n, bool cast, uin
     if (rc) return rc;
     DevBuf d_rays, d_ent, d_tri, d_t, d_pos, d_nrm, d_col, d_stats;
     HIP_TRY(d_rays.upload(rays, (size_t)n * 48));
-    HIP_TRY(d_stats.ensure(32));
-    HIP_TRY(hipMemset(d_stats.p, 0, 32));
+    HIP_TRY(d_stats.ensure(64));
+    HIP_TRY(hipMemset(d_stats.p, 0, 64));
     if (cast) {
         HIP_TRY(d_col.ensure((size_t)n * 24));
         rrt::launch_cast_rays(s->dscene, d_rays.as<double>(), n, max_bounce, prune, d_col.as<double>(),
@@ -894,6 +986,27 @@ static int ray_query(rrt_scene* s, const double* rays, int64_t n, bool cast, uin
     if (pos) HIP_TRY(hipMemcpy(pos, d_pos.p, (size_t)n * 24, hipMemcpyDeviceToHost));
     if (nrm) HIP_TRY(hipMemcpy(nrm, d_nrm.p, (size_t)n * 24, hipMemcpyDeviceToHost));
     return RRT_OK;
+}
+
+int rrt_occluded_rays(rrt_scene* s, const double* rays, const double* max_dist2, int64_t n, uint8_t* out) try {
+    if (!s || !rays || !max_dist2 || !out || n < 0) return fail(RRT_E_INVALID, "bad argument");
+    if (n == 0) return RRT_OK;
+    int rc = commit(s);
+    if (rc) return rc;
+    DevBuf d_rays, d_lim, d_out, d_stats;
+    HIP_TRY(d_rays.upload(rays, (size_t)n * 48));
+    HIP_TRY(d_lim.upload(max_dist2, (size_t)n * 8));
+    HIP_TRY(d_out.ensure((size_t)n));
+    HIP_TRY(d_stats.ensure(64));
+    HIP_TRY(hipMemset(d_stats.p, 0, 64));
+    rrt::launch_occluded_rays(s->dscene, d_rays.as<double>(), d_lim.as<double>(), n, d_out.as<uint8_t>(),
+                              d_stats.as<unsigned long long>(), nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out, d_out.p, (size_t)n, hipMemcpyDeviceToHost));
+    return RRT_OK;
+} catch (...) {
+    return on_exception();
 }
 
 int rrt_trace_rays(rrt_scene* s, const double* rays, int64_t n, int32_t* ent, int32_t* tri, double* t, double* pos,

@@ -69,7 +69,7 @@ struct DMesh {
     const DBox32* grp;      // per group of kGroup consecutive stream entries: union of their cull boxes
                             // (tris and grp carry kStreamPad extra entries for the loops to run into)
     int32_t material;
-    int32_t n_nodes;
+    int32_t flags;          // kTreeStaleBoxes
     // constants of the conservative cull (host-computed, f64)
     double center[3];       // root box centre
     double radius;          // root box half diagonal
@@ -96,6 +96,14 @@ struct DMaterial {
     double ior;
 };
 
+// PointLight{position, color, brightness, attenuation} (lighting.rs:52-57)
+struct DPointLight {
+    double pos[3];
+    double color[3];
+    double brightness, attenuation;
+};
+constexpr int32_t kMaxPointLights = 16;
+
 struct DEntity {
     int32_t kind;   // 0 sphere, 1 mesh, 2 group (Scene<T>); | kEntityMember when it lives inside a group
     int32_t index;
@@ -109,7 +117,14 @@ struct DGroup {
     const DBox* boxes;
     const DLeaf* leaves;
     const int32_t* members;
+    int32_t flags;          // kTreeStaleBoxes
+    int32_t pad;
 };
+// The tree went through a literal rrt_translate_entity (refit = 0; kdtree.rs:35-42 moves the split planes and forgets
+// the boxes): a leaf's box need not contain the point find_point arrived with any more, so the leaf exit has to be
+// the reference's full AABB::collide (aabb.rs:50-100, negative -> position (0,0,0), kdtree.rs:221-222), not its
+// inside arm alone.
+constexpr int32_t kTreeStaleBoxes = 1;
 
 struct DScene {
     const DEntity* ents;
@@ -133,6 +148,9 @@ struct DScene {
     int32_t lds_nodes;       // its node count (LDS bytes = 16 * lds_nodes)
     int32_t cull_mode;       // 0 = off, 1 = on, 2 = verify (run both, count cull-vs-exact disagreements)
     int32_t lds_ents;        // 1: the trace kernels keep the entity table in LDS (n_ents <= kMaxLdsEnts)
+    const DPointLight* plights;   // world.light_sources behind the directional light, in push order
+    int32_t n_plights;
+    int32_t shadow_mode;     // PointLight::visible: 0 = as the reference wrote it, 1 = corrected (rrt_set_shadow_mode)
 };
 
 constexpr int32_t kGroup = 4;            // a leaf's run in the stream starts at a multiple of kGroup and is padded to one
@@ -178,6 +196,8 @@ void launch_trace_rays(const DScene& sc, const double* d_rays, int64_t n, int32_
                        double* pos, double* nrm, unsigned long long* stats, void* stream);
 void launch_cast_rays(const DScene& sc, const double* d_rays, int64_t n, uint32_t max_bounce, uint32_t prune,
                       double* color, unsigned long long* stats, void* stream);
+void launch_occluded_rays(const DScene& sc, const double* d_rays, const double* d_lim2, int64_t n, uint8_t* out,
+                          unsigned long long* stats, void* stream);
 void launch_selftest(int op, const double* a, const double* b, int64_t n, double* out, void* stream);
 
 // Scratch of the entry point that allocates nothing (rrt_render_device_noalloc): a file-scope

@@ -199,6 +199,18 @@ RRT_DEV V3 box_exit(V3 mn, V3 mx, V3 o, V3 d, V3 inv) {
     return o + d * t;
 }
 
+// The leaf exit of kdtree.rs:221-222 when nothing is known about where the point lies (trees whose boxes went
+// stale through a literal translate): the full AABB::collide; its collision flag is ignored by the caller and a
+// negative result carries the position (0,0,0) (ColliderResult::negative, common.rs:57-72).
+#ifndef RRT_COLD
+#define RRT_COLD __device__ __forceinline__
+#endif
+RRT_COLD V3 leaf_exit_general(V3 mn, V3 mx, V3 o, V3 d, V3 inv) {
+    V3 pos;
+    if (!box_collide(mn, mx, o, d, inv, &pos)) pos = mk(0., 0., 0.);
+    return pos;
+}
+
 // ---------------------------------------------------------------------------
 // Triangle::collide (triangle.rs:25-58) on the pre-subtracted edges.
 // ---------------------------------------------------------------------------
@@ -384,9 +396,14 @@ RRT_DEV void leaf_test(const TriData& T, int32_t entry, V3 o, V3 d, LeafBest* b)
 }
 
 // KDTree::collide (kdtree.rs:192-235).  Returns the winning stream entry in out->entry (-1 = miss).
-template <int CULL>
+// ANY (shadow rays): the any-hit variant.  The caller only wants to know whether this collide() answers with a
+// hit closer than lim2 (squared distance; kF64Max = "any hit at all"), so the walk returns at the first accepted
+// triangle that is close enough -- out->dist < lim2 then -- instead of finishing the leaf for the closest one.
+// A leaf whose accepted triangles are all farther still ends the walk (kdtree.rs:214: the first leaf with any hit
+// answers), with out->entry >= 0 and out->dist >= lim2: "hit, but not an occluder".
+template <int CULL, bool ANY = false>
 RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnodes, V3 o, V3 d, LeafBest* out,
-                          unsigned long long* stats) {
+                          unsigned long long* stats, double lim2 = 0.0) {
     out->entry = -1; out->dist = kF64Max; out->t = 0.0;
     CNT(1);
     const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);   // aabb.rs:74, same for every box test of this ray
@@ -425,6 +442,7 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
                 leaf_test(A, first + k, o, d, &best);
                 A = ld_tri(tp + k + 2);
                 if (k + 1 < count) leaf_test(B, first + k + 1, o, d, &best);
+                if (ANY && best.dist < lim2) break;
             }
         } else {
             // Three phases per chunk of up to 32 stream entries (8 groups of kGroup = 4).
@@ -477,7 +495,9 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
                         if (tri_collide(T, o, d, &t)) atomicAdd(&stats[2], 1ull);
                     }
                     leaf_test(T, first + e, o, d, &best);
+                    if (ANY && best.dist < lim2) break;
                 }
+                if (ANY && best.dist < lim2) break;
             }
         }
         if (best.entry >= 0) {
@@ -492,7 +512,8 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
         const V3 mn = ld3g(L->mn), mx = ld3g(L->mx);
         const i32x4 r03 = *(const RRT_GLOBAL i32x4*)&L->rope[0];
         const i32x2 r45 = *(const RRT_GLOBAL i32x2*)&L->rope[4];
-        point = box_exit(mn, mx, point, d, inv) + d * 0.001;
+        if (M.flags & kTreeStaleBoxes) point = leaf_exit_general(mn, mx, point, d, inv) + d * 0.001;
+        else point = box_exit(mn, mx, point, d, inv) + d * 0.001;
         const int pl = get_plane(point, mn, mx);
         const int32_t nb = pl == 0 ? r03.x : pl == 1 ? r03.y : pl == 2 ? r03.z : pl == 3 ? r03.w : pl == 4 ? r45.x : r45.y;
         if (nb < 0) return;
@@ -603,9 +624,9 @@ RRT_DEV T lds_uniform(const RRT_LDS uint32_t* p) {
 // loop (tracer.rs:183-188) and a kd leaf over entities (kdtree.rs:204-211) apply: strict <, so the
 // first of equals stays.
 // `rec` != nullptr: entity e's LDS record (e is wave-uniform then); nullptr: read from global memory.
-template <int CULL, bool REC>
+template <int CULL, bool REC, bool ANY = false>
 RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LDS uint32_t* rec, int32_t e, DEntity ent,
-                            V3 o, V3 d, int32_t medium, Closest* best, unsigned long long* stats) {
+                            V3 o, V3 d, int32_t medium, Closest* best, unsigned long long* stats, double lim2 = 0.0) {
     if ((RRT_ABL & 4) && ent.kind == 0) return;
     if ((RRT_ABL & 2) && ent.kind != 0) return;
     if (ent.kind == 0) {
@@ -630,7 +651,7 @@ RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LD
             K = CullConst{{M.center[0], M.center[1], M.center[2]}, M.radius, M.edge_max, M.abs_max};
         }
         LeafBest h;
-        mesh_collide<CULL>(M, K, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, &h, stats);
+        mesh_collide<CULL, ANY>(M, K, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, &h, stats, lim2);
         // same |pos - origin|^2 as the leaf-level metric (kdtree.rs:206 == tracer.rs:184)
         if (h.entry >= 0 && h.dist < best->dist) {
             best->dist = h.dist; best->t = h.t; best->ent = e; best->entry = h.entry;
@@ -641,9 +662,9 @@ RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LD
 // Scene<T>::collide (scene.rs:50-52) = KDTree<T>::collide (kdtree.rs:192-235) with whole entities in
 // the leaves: the closest member of the first leaf in which any member answers.  `out` receives
 // that member (its entity id), or ent = -1.
-template <int CULL>
+template <int CULL, bool ANY = false>
 RRT_DEV void group_collide(const DScene& sc, const DGroup& G, const DNodeI* lnodes, V3 o, V3 d, int32_t medium,
-                           Closest* out, unsigned long long* stats) {
+                           Closest* out, unsigned long long* stats, double lim2 = 0.0) {
     out->dist = kF64Max; out->t = 0.0; out->ent = -1; out->entry = -1;
     const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
     V3 point;
@@ -666,7 +687,8 @@ RRT_DEV void group_collide(const DScene& sc, const DGroup& G, const DNodeI* lnod
             const int32_t e = members[lr.first + k];
             DEntity ent = sc.ents[e];
             ent.kind &= ~kEntityMember;            // 0 sphere or 1 mesh (rrt_add_group admits nothing else)
-            entity_collide<CULL, false>(sc, lnodes, nullptr, e, ent, o, d, medium, &best, stats);   // e differs per lane
+            entity_collide<CULL, false, ANY>(sc, lnodes, nullptr, e, ent, o, d, medium, &best, stats, lim2);   // e differs per lane
+            if (ANY && best.dist < lim2) break;
         }
         if (best.ent >= 0) {
             *out = best;
@@ -674,7 +696,8 @@ RRT_DEV void group_collide(const DScene& sc, const DGroup& G, const DNodeI* lnod
         }
         const RRT_GLOBAL DLeaf* L = as_global(G.leaves) + lr.leaf;
         const V3 mn = ld3g(L->mn), mx = ld3g(L->mx);
-        point = box_exit(mn, mx, point, d, inv) + d * 0.001;
+        if (G.flags & kTreeStaleBoxes) point = leaf_exit_general(mn, mx, point, d, inv) + d * 0.001;
+        else point = box_exit(mn, mx, point, d, inv) + d * 0.001;
         const int32_t nb = L->rope[get_plane(point, mn, mx)];
         if (nb < 0) return;
         lr = find_point(G.nodes, G.boxes, nullptr, nb, point);
@@ -711,6 +734,57 @@ RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, 
         }
         entity_collide<CULL, LDS::kSmall>(sc, lnodes, rec, e, ent, o, d, medium, best, stats);
     }
+}
+
+// The any-hit question of a shadow ray: does some entity of world.entities answer the ray (o, d) with a collision
+// closer than lim2 (squared distance of its position from o)?  Same entity order and Entity::collide semantics as
+// closest_hit; stops at the first occluder.  LITERAL (lighting.rs:77-82 as written): returns true as soon as one
+// entity does NOT collide at all ("visible"), false when every entity collides.
+template <int CULL, bool GROUPS, bool LITERAL, class LDS>
+RRT_DEV bool any_hit(const DScene& sc, LDS lds, V3 o, V3 d, double lim2, unsigned long long* stats) {
+    const DNodeI* lnodes = lds.nodes;
+    for (int32_t e = 0; e < sc.n_ents; ++e) {
+        const RRT_LDS uint32_t* rec = nullptr;
+        DEntity ent;
+        if constexpr (LDS::kSmall) {
+            rec = lds.ents + e * kEntRec;
+            ent = lds_uniform<DEntity>(rec);
+        } else {
+            ent = sc.ents[e];
+        }
+        Closest h;
+        h.dist = kF64Max; h.t = 0.0; h.ent = -1; h.entry = -1;
+        if (GROUPS) {
+            if (ent.kind & kEntityMember) continue;
+            if (ent.kind == 2) {
+                DGroup G;
+                if constexpr (LDS::kSmall) G = lds_uniform<DGroup>(rec + 2);
+                else G = sc.groups[ent.index];
+                group_collide<CULL, true>(sc, G, lnodes, o, d, -1, &h, stats, lim2);
+                if (LITERAL) { if (h.ent < 0) return true; }
+                else if (h.ent >= 0 && h.dist < lim2) return true;
+                continue;
+            }
+        }
+        entity_collide<CULL, LDS::kSmall, true>(sc, lnodes, rec, e, ent, o, d, -1, &h, stats, lim2);
+        if (LITERAL) { if (h.ent < 0) return true; }
+        else if (h.ent >= 0 && h.dist < lim2) return true;
+    }
+    return false;
+}
+
+// PointLight::visible.  shadow_mode 0: lighting.rs:70-84 exactly as written -- the ray starts on the surface, its
+// direction (light - pos) is not normalised, and the answer is "visible" as soon as ONE entity is missed (inverted
+// with respect to a shadow test; restated because it is what the code says).  shadow_mode 1 (EXTENSION, see
+// rrt_set_shadow_mode): the surface must face the light, the ray starts at pos + normal*0.3, is normalised, and the
+// light is visible iff nothing is hit closer than the light.
+template <int CULL, bool GROUPS, class LDS>
+RRT_DEV bool point_light_visible(const DScene& sc, LDS lds, V3 lpos, V3 pos, V3 normal, unsigned long long* stats) {
+    if (sc.shadow_mode == 0) return any_hit<CULL, GROUPS, true>(sc, lds, pos, lpos - pos, kF64Max, stats);
+    if (!(dot(normal, pos - lpos) < 0.)) return false;
+    const V3 o = pos + normal * 0.3;
+    const V3 v = lpos - o;
+    return !any_hit<CULL, GROUPS, false>(sc, lds, o, normalize(v), mag2(v), stats);
 }
 
 // Rebuilds the ColliderResult of the winning entity: position (sphere.rs:39 / triangle.rs:53),
@@ -827,8 +901,11 @@ RRT_DEV V3 sky_color(const DScene& sc, LDS lds, V3 dir) {
 
 // Direct terms of a hit (tracer.rs:194-202 with lambert.rs:22-45, phong.rs:25-47):
 //   A  = color*ambient + Lambert*mixL      Pm = Phong*mixP
-template <class LDS>
-RRT_DEV void shade_direct(const DScene& sc, LDS lds, const DMaterial& m, V3 d, V3 normal, V3* A, V3* Pm) {
+// PL: the world holds PointLights behind the directional light (light_sources order: lambert.rs:34, phong.rs:37);
+// a compile-time flag, because their visible() walks the scene again (shadow rays) from inside the shading.
+template <int CULL, bool GROUPS, bool PL, class LDS>
+RRT_DEV void shade_direct(const DScene& sc, LDS lds, const DMaterial& m, V3 d, V3 pos, V3 normal, V3* A, V3* Pm,
+                          unsigned long long* stats) {
     const V3 color = ld3(m.color);
     double ambient, intensity;
     V3 L, lcolor;
@@ -849,6 +926,23 @@ RRT_DEV void shade_direct(const DScene& sc, LDS lds, const DMaterial& m, V3 d, V
         const V3 bis = normalize(neg(L) - d);
         const double pw = intensity * powi(fmax(dot(bis, normal), 0.), m.alpha);
         ph = ph + lcolor * pw;
+    }
+    if constexpr (PL) {
+        for (int32_t k = 0; k < sc.n_plights; ++k) {
+            const DPointLight L = sc.plights[k];
+            const V3 lpos = ld3(L.pos);
+            if (!point_light_visible<CULL, GROUPS>(sc, lds, lpos, pos, normal, stats)) continue;
+            const V3 dir0 = pos - lpos;                                   // lighting.rs:61-67
+            const double distance2 = mag2(dir0);
+            const V3 dir = normalize(dir0);
+            const double lp = L.brightness / (L.attenuation * distance2);
+            double power = lp * (m.albedo / 3.14159265358979323846) * -dot(normal, dir);
+            power = fmax(power, 0.);
+            lam = lam + color * power;
+            const V3 bis = normalize(neg(dir) - d);
+            const double pw = lp * powi(fmax(dot(bis, normal), 0.), m.alpha);
+            ph = ph + ld3(L.color) * pw;
+        }
     }
     *A = fin + lam * m.mixL;
     *Pm = ph * m.mixP;
@@ -1016,7 +1110,7 @@ RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y
 }
 
 // One cast() (tracer.rs:177-211) of path `path` at depth `bounce`.
-template <bool PRIMARY, int CULL, bool GROUPS, class LDS>
+template <bool PRIMARY, int CULL, bool GROUPS, bool PL, class LDS>
 RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFrame& fr, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
                          uint32_t pixel, uint32_t sample, bool dead_sky = false, unsigned long long* tacc = nullptr) {
@@ -1045,7 +1139,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             const DMaterial m = load_material(sc, lds, h.mat);
             V3 A, Pm;
             CNT(9);
-            shade_direct(sc, lds, m, d, h.normal, &A, &Pm);
+            shade_direct<CULL, GROUPS, PL>(sc, lds, m, d, h.pos, h.normal, &A, &Pm, wk.stats);
             cont = !(bounce > fr.max_bounce) && !(fr.prune && m.mixR == 0.0);
             if (cont) {
                 zero_mix = m.mixR == 0.0;
@@ -1232,7 +1326,7 @@ RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned 
 
 // Persistent blocks: block b takes path tiles b, b + grid, ... (neighbouring tiles, which cost
 // about the same, go to different blocks), so the LDS staging is paid once per block.
-template <int CULL, bool GROUPS, bool SMALL>
+template <int CULL, bool GROUPS, bool SMALL, bool PL>
 __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
     extern __shared__ __align__(16) unsigned char smem[];
     const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, true);
@@ -1267,7 +1361,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         const uint32_t sample = fr.s0 + s_local;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         if (active) primary_ray(fr, lds, x, y, sample, &o, &d);
-        process_ray<true, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample);
+        process_ray<true, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample);
     }
 }
 
@@ -1276,7 +1370,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
 // more than an order of magnitude (a reflection that leaves the UFO at once vs. one that walks a
 // dozen leaves inside it); with one fixed 64-ray slice per wave and round, a block kept its LDS and
 // register slots until its slowest wave was done (measured: 2.4 of 4 waves/SIMD resident).
-template <int CULL, bool GROUPS, bool SMALL>
+template <int CULL, bool GROUPS, bool SMALL, bool PL>
 __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t n_live = wk.q_count[bounce], n_dead = wk.q_count[kMaxLevels + 1 + bounce], count = n_live + n_dead;
@@ -1326,7 +1420,7 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
         }
         const unsigned long long t1 = TSTAMP();
         unsigned long long tch = 0;
-        process_ray<false, CULL, GROUPS>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, dead_sky, &tch);
+        process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, dead_sky, &tch);
         const unsigned long long t2 = TSTAMP();
         if (__ballot(active && !dead_sky) != 0ull) acc_lc += tch;
         acc_q += t1 - t0; acc_p += t2 - t1; acc_n += 1;
@@ -1431,7 +1525,7 @@ __global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* ray
 }
 
 // cast() as one thread per ray with a private record stack (test / probe API).
-template <bool GROUPS>
+template <bool GROUPS, bool PL>
 __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays, int64_t n, uint32_t max_bounce,
                                                    uint32_t prune, double* color, unsigned long long* stats) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1453,7 +1547,9 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
         if (!h.hit) { col = sky_color(sc, kNoLds, d); break; }
         const DMaterial m = sc.mats[h.mat];
         V3 A, Pm;
-        shade_direct(sc, kNoLds, m, d, h.normal, &A, &Pm);
+        if (sc.cull_mode == 0) shade_direct<0, GROUPS, PL>(sc, kNoLds, m, d, h.pos, h.normal, &A, &Pm, stats);
+        else if (sc.cull_mode == 1) shade_direct<1, GROUPS, PL>(sc, kNoLds, m, d, h.pos, h.normal, &A, &Pm, stats);
+        else shade_direct<2, GROUPS, PL>(sc, kNoLds, m, d, h.pos, h.normal, &A, &Pm, stats);
         const bool cont = !(bounce > max_bounce) && !(prune && m.mixR == 0.0);
         if (!cont) { col = A + Pm; break; }
         sA[bounce] = A; sP[bounce] = Pm; sR[bounce] = m.mixR;
@@ -1463,6 +1559,21 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
     }
     for (uint32_t k = bounce; k-- > 0;) col = (sA[k] + col * sR[k]) + sP[k];
     color[3 * i] = col.x; color[3 * i + 1] = col.y; color[3 * i + 2] = col.z;
+}
+
+// The any-hit walk for caller rays (shadow-ray API): out[i] = 1 iff some entity answers ray i closer than lim2[i].
+template <bool GROUPS>
+__global__ __launch_bounds__(256) void k_occluded_rays(DScene sc, const double* rays, const double* lim2, int64_t n,
+                                                       uint8_t* out, unsigned long long* stats) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
+    const double lim = lim2[i];
+    bool r;
+    if (sc.cull_mode == 0) r = any_hit<0, GROUPS, false>(sc, kNoLds, o, d, lim, stats);
+    else if (sc.cull_mode == 1) r = any_hit<1, GROUPS, false>(sc, kNoLds, o, d, lim, stats);
+    else r = any_hit<2, GROUPS, false>(sc, kNoLds, o, d, lim, stats);
+    out[i] = r ? 1 : 0;
 }
 
 __global__ void k_selftest(int op, const double* a, const double* b, int64_t n, double* out) {
@@ -1500,26 +1611,33 @@ inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) 
 
 }  // namespace
 
+// Kernel variant by scene: cull mode x (Scene<T> groups present) x (entity table in LDS) x (point lights present).
+// A world with point lights always takes the GROUPS instantiation (it handles group-less worlds too), so the
+// shadow-ray code is compiled 6 times per kernel, not 12.
+#define RRT_PICK(name)                                                                                           \
+    [&]() {                                                                                                      \
+        const bool pl = sc.n_plights > 0, g = sc.n_groups > 0 || pl, sm = sc.lds_ents != 0;                      \
+        const int c = sc.cull_mode;                                                                              \
+        if (pl) {                                                                                                \
+            if (sm) return c == 0 ? name<0, true, true, true> : c == 1 ? name<1, true, true, true> : name<2, true, true, true>;      \
+            return c == 0 ? name<0, true, false, true> : c == 1 ? name<1, true, false, true> : name<2, true, false, true>;           \
+        }                                                                                                        \
+        if (g) {                                                                                                 \
+            if (sm) return c == 0 ? name<0, true, true, false> : c == 1 ? name<1, true, true, false> : name<2, true, true, false>;   \
+            return c == 0 ? name<0, true, false, false> : c == 1 ? name<1, true, false, false> : name<2, true, false, false>;        \
+        }                                                                                                        \
+        if (sm) return c == 0 ? name<0, false, true, false> : c == 1 ? name<1, false, true, false> : name<2, false, true, false>;    \
+        return c == 0 ? name<0, false, false, false> : c == 1 ? name<1, false, false, false> : name<2, false, false, false>;         \
+    }()
+
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
     const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
     const uint32_t grid = (uint32_t)(chunks < trace_grid() ? chunks : trace_grid());
-    const auto pick = [&](auto g, auto sm) {
-        constexpr bool G = decltype(g)::value, S = decltype(sm)::value;
-        return sc.cull_mode == 0 ? k_wave_primary<0, G, S> : sc.cull_mode == 1 ? k_wave_primary<1, G, S> : k_wave_primary<2, G, S>;
-    };
-    using T = std::true_type;
-    using F = std::false_type;
-    auto k = sc.n_groups > 0 ? (sc.lds_ents ? pick(T{}, T{}) : pick(T{}, F{})) : (sc.lds_ents ? pick(F{}, T{}) : pick(F{}, F{}));
+    auto k = RRT_PICK(k_wave_primary);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, d_ids, d_t);
 }
 void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream) {
-    const auto pick = [&](auto g, auto sm) {
-        constexpr bool G = decltype(g)::value, S = decltype(sm)::value;
-        return sc.cull_mode == 0 ? k_wave_bounce<0, G, S> : sc.cull_mode == 1 ? k_wave_bounce<1, G, S> : k_wave_bounce<2, G, S>;
-    };
-    using T = std::true_type;
-    using F = std::false_type;
-    auto k = sc.n_groups > 0 ? (sc.lds_ents ? pick(T{}, T{}) : pick(T{}, F{})) : (sc.lds_ents ? pick(F{}, T{}) : pick(F{}, F{}));
+    auto k = RRT_PICK(k_wave_bounce);
     hipLaunchKernelGGL(k, dim3(bounce_grid()), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
 }
 void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream) {
@@ -1540,8 +1658,14 @@ void launch_trace_rays(const DScene& sc, const double* d_rays, int64_t n, int32_
 }
 void launch_cast_rays(const DScene& sc, const double* d_rays, int64_t n, uint32_t max_bounce, uint32_t prune,
                       double* color, unsigned long long* stats, void* stream) {
-    hipLaunchKernelGGL(sc.n_groups > 0 ? k_cast_rays<true> : k_cast_rays<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sc, d_rays,
-                       n, max_bounce, prune, color, stats);
+    auto k = sc.n_plights > 0 ? k_cast_rays<true, true> : sc.n_groups > 0 ? k_cast_rays<true, false> : k_cast_rays<false, false>;
+    hipLaunchKernelGGL(k, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sc, d_rays, n, max_bounce, prune,
+                       color, stats);
+}
+void launch_occluded_rays(const DScene& sc, const double* d_rays, const double* d_lim2, int64_t n, uint8_t* out,
+                          unsigned long long* stats, void* stream) {
+    hipLaunchKernelGGL(sc.n_groups > 0 ? k_occluded_rays<true> : k_occluded_rays<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, sc, d_rays, d_lim2, n, out, stats);
 }
 void launch_selftest(int op, const double* a, const double* b, int64_t n, double* out, void* stream) {
     hipLaunchKernelGGL(k_selftest, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, op, a, b, n,

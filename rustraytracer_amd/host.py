@@ -129,6 +129,24 @@ class World:
     def set_ambient(self, a):
         B.check(B.lib.rrt_set_ambient(self.h, float(a)))
 
+    def add_point_light(self, position, color, brightness, attenuation):
+        """PointLight{position, color, brightness, attenuation} (lighting.rs:52-57) pushed to world.light_sources."""
+        return B.check(B.lib.rrt_add_point_light(self.h, _d3(position), _d3(color), float(brightness), float(attenuation)))
+
+    def set_shadow_mode(self, mode):
+        B.check(B.lib.rrt_set_shadow_mode(self.h, int(mode)))
+
+    def translate(self, ent, vec, refit=0):
+        """Entity::translate (sphere.rs:68-70, model.rs:80-86, scene.rs:68-74); refit=1 also moves the boxes."""
+        B.check(B.lib.rrt_translate_entity(self.h, int(ent), _d3(vec), int(refit)))
+
+    def occluded_rays(self, rays, lim2):
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        lim2 = np.ascontiguousarray(np.broadcast_to(np.asarray(lim2, dtype=np.float64), (rays.shape[0],)))
+        out = np.zeros(rays.shape[0], np.uint8)
+        B.check(B.lib.rrt_occluded_rays(self.h, _ptr(rays), _ptr(lim2), rays.shape[0], _ptr(out)))
+        return out
+
     def set_work_budget(self, nbytes):
         B.check(B.lib.rrt_set_work_budget(self.h, int(nbytes)))
 

@@ -219,3 +219,40 @@ def test_max_bounce_is_range_checked_before_any_launch(H):
         assert B.lib.rrt_render_device(w.h, C.byref(cam), C.byref(st), None, None, None, None, None) == -1
         assert B.lib.rrt_cast_rays(w.h, rays.ctypes.data, 2, mb, 0, col.ctypes.data) == -1
         assert b"max_bounce" in B.lib.rrt_last_error()
+
+
+def test_translate_host_side_matches_oracle_and_rebuild(H, O, scenes):
+    """rrt_translate_entity on the host (no GPU): literal = split planes move and boxes stay
+    (kdtree.rs:35-42), refit = boxes follow; both equal the oracle's restatement array for array, and a
+    refit translation by an exactly representable vector equals the tree built at the new place."""
+    import os
+    p = os.path.join(scenes.ASSETS, "obj", "ufo_fix.obj")
+    v, n = H.loaders.load_model(p, (0.0, 30.0, 70.0), (1.0, -1.0, 1.0))
+    vec = (4.0, -2.0, 8.0)
+    for refit in (0, 1):
+        g, c = H.World(), O.OracleScene()
+        for s in (g, c):
+            s.add_mesh(v, n, s.add_material((0.5, 0.5, 0.5), 1.0, 1.0, 0.0, 0.3, 20))
+        before = g.tree(0)
+        g.translate(0, vec, refit); c.translate(0, vec, refit)
+        tg, tc = g.tree(0), c.tree(0)
+        assert all(np.array_equal(tg[k], tc[k]) for k in tg)
+        interior = before["axis"] >= 0
+        assert np.array_equal(tg["split"][interior], before["split"][interior] + np.array(vec)[before["axis"][interior]])
+        if refit:
+            fresh = H.World()
+            fresh.add_mesh(v + np.array(vec), n, fresh.add_material((0.5, 0.5, 0.5), 1.0, 1.0, 0.0, 0.3, 20))
+            tf = fresh.tree(0)
+            assert all(np.array_equal(tg[k], tf[k]) for k in tg)
+        else:
+            assert np.array_equal(tg["boxes"], before["boxes"])          # the reference forgets them
+    from rustraytracer_amd import binding as B
+    w = H.World()
+    with pytest.raises(B.RrtError, match="unknown entity"):
+        w.translate(0, vec)
+    for i in range(16):
+        assert w.add_point_light((0, 0, 0), (1, 1, 1), 1.0, 1.0) == i
+    with pytest.raises(B.RrtError, match="too many"):
+        w.add_point_light((0, 0, 0), (1, 1, 1), 1.0, 1.0)
+    with pytest.raises(B.RrtError, match="shadow mode"):
+        w.set_shadow_mode(2)

@@ -192,3 +192,57 @@ def test_spp1_is_reference_and_jitter_stays_in_pixel(O):
         p = r[3:] * (75.0 / r[5])
         fx = (p[0] + 80) / 160 * 640; fy = (p[1] + 45) / 90 * 480
         assert 10 <= fx < 11 and 20 <= fy < 21
+
+
+def test_point_light_known_answers(O, scenes):
+    """PointLight (lighting.rs:52-89) has no golden in the reference (dead code): the oracle's restatement is
+    pinned to the impl block's own formulas evaluated by hand in numpy -- illuminate's power and direction,
+    Lambert's and Phong's sums (lambert.rs:38-41, phong.rs:41-43) -- and to the two visible() definitions:
+    as written (visible as soon as one entity is missed) and corrected (blocked by the sphere in between)."""
+    import numpy as np
+    from oracle import oracle as Om
+
+    def build(blocker):
+        c = Om.OracleScene()
+        c.set_sky(Om.load_cubemap(os.path.join(scenes.ASSETS, "cubemaps", "sky")))
+        c.set_ambient(0.15)                                   # no directional light: only the point light shines
+        m = c.add_material((0.5, 0.25, 0.125), 0.8, 1.0, 0.0, 0.5, 20)
+        c.add_sphere((0.0, 0.0, 10.0), 2.0, m)
+        if blocker:
+            c.add_sphere((0.0, -2.5, 5.5), 1.0, m)
+        c.add_point_light((0.0, -5.0, 3.0), (1.0, 0.5, 0.25), 300.0, 2.0)
+        return c
+    ray = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 1.0]])
+    pos, n, d = np.array([0.0, 0.0, 8.0]), np.array([0.0, 0.0, -1.0]), np.array([0.0, 0.0, 1.0])
+    color, lcol, L = np.array([0.5, 0.25, 0.125]), np.array([1.0, 0.5, 0.25]), np.array([0.0, -5.0, 3.0])
+    dot = lambda a, b: (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+    norm = lambda v: v * (1.0 / np.sqrt(dot(v, v)))
+    dir0 = pos - L
+    power = 300.0 / (2.0 * dot(dir0, dir0))
+    dirn = norm(dir0)
+    lam = color * max(power * (0.8 / np.pi) * -dot(n, dirn), 0.0)
+    bis = norm(-dirn - d)
+    x = max(dot(bis, n), 0.0)
+    x2 = x * x; x4 = x2 * x2; x8 = x4 * x4; x16 = x8 * x8
+    ph = lcol * (power * (x4 * x16))
+    lit = ((color * 0.15 + (np.zeros(3) + lam) * 1.0) + (np.zeros(3) + ph) * 0.5)
+    unlit = ((color * 0.15 + np.zeros(3) * 1.0) + np.zeros(3) * 0.5)
+    for mode in (0, 1):
+        c = build(False)
+        c.set_shadow_mode(mode)
+        assert np.array_equal(c.cast_rays(ray, 0, 1)[0], lit), mode          # nothing in the way: both definitions say lit
+    c = build(True)
+    c.set_shadow_mode(1)
+    assert np.array_equal(c.cast_rays(ray, 0, 1)[0], unlit)                  # corrected: the blocker casts a shadow
+    c.set_shadow_mode(0)
+    assert np.array_equal(c.cast_rays(ray, 0, 1)[0], lit)                    # as written: the first entity is missed -> "visible"
+    # as written, a world whose every entity is hit by the (un-normalised) shadow ray is dark
+    c = Om.OracleScene()
+    c.set_sky(Om.load_cubemap(os.path.join(scenes.ASSETS, "cubemaps", "sky")))
+    m = c.add_material((0.5, 0.25, 0.125), 0.8, 1.0, 0.0, 0.5, 20)
+    c.add_sphere((0.0, 0.0, 10.0), 2.0, m)
+    c.add_point_light((0.0, 0.0, 20.0), (1.0, 1.0, 1.0), 300.0, 2.0)         # behind the sphere: the ray from pos runs through it
+    assert np.array_equal(c.cast_rays(ray, 0, 1)[0], unlit)
+    # any-hit query: limits before / behind the hit
+    c = build(False)
+    assert list(c.occluded_rays(np.repeat(ray, 3, axis=0), [63.9, 64.0, 64.1])) == [0, 0, 1]
