@@ -194,8 +194,9 @@ int commit(rrt_scene* s) {
         // Leaf-ordered stream, every leaf's run aligned to kGroup entries and padded to a multiple of
         // it (pad = copy of the run's last entry, never tested: the kernels mask by the leaf's count).
         constexpr int32_t G = rrt::kGroup;
-        std::vector<int32_t> refs;
+        std::vector<rrt::DRef> refs;
         refs.reserve(T.leaf_refs.size() + (size_t)G * leaves.size());
+        std::vector<std::pair<uint32_t, int32_t>> order;      // (Morton key, position in the reference's leaf list)
         std::vector<int32_t> leaf_node(leaves.size());
         for (size_t k = 0; k < nn; ++k)
             if (nodes[k].axis < 0) leaf_node[(size_t)nodes[k].right] = (int32_t)k;
@@ -205,15 +206,37 @@ int commit(rrt_scene* s) {
             L.first = (int32_t)refs.size();
             nodes[(size_t)leaf_node[li]].run[0] = L.first;
             nodes[(size_t)leaf_node[li]].run[1] = L.count;
-            for (int32_t k = 0; k < L.count; ++k) refs.push_back(T.leaf_refs[(size_t)src + k]);
+            // spatial order inside the leaf: Morton code of the triangle centroids within their own bounds (10 bits
+            // an axis), ties in list order; the list position goes along as the rank that decides equal distances
+            order.clear();
+            double cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            const auto centroid = [&](int32_t tri, int a) { const rrt::DTri& t = m.tris[(size_t)tri]; return t.v0[a] + (t.e1[a] + t.e2[a]) / 3.0; };
+            for (int32_t k = 0; k < L.count; ++k)
+                for (int a = 0; a < 3; ++a) {
+                    const double c = centroid(T.leaf_refs[(size_t)src + k], a);
+                    cmn[a] = std::fmin(cmn[a], c);
+                    cmx[a] = std::fmax(cmx[a], c);
+                }
+            for (int32_t k = 0; k < L.count; ++k) {
+                uint32_t key = 0;
+                for (int a = 0; a < 3; ++a) {
+                    const double ext = cmx[a] - cmn[a];
+                    double f = ext > 0.0 ? (centroid(T.leaf_refs[(size_t)src + k], a) - cmn[a]) / ext : 0.0;
+                    if (!(f >= 0.0)) f = 0.0;
+                    uint32_t q = (uint32_t)std::fmin(f * 1024.0, 1023.0);
+                    for (int bit = 0; bit < 10; ++bit) key |= ((q >> bit) & 1u) << (3 * bit + a);
+                }
+                order.emplace_back(key, k);
+            }
+            std::stable_sort(order.begin(), order.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+            for (const auto& kv : order) refs.push_back(rrt::DRef{T.leaf_refs[(size_t)src + kv.second], kv.second});
             while (refs.size() % G) refs.push_back(refs.back());
         }
         if (refs.size() > 0x7fffffffull - 64) return fail(RRT_E_INVALID, "mesh too large (triangle stream index exceeds 31 bits)");
         HIP_TRY(m.d_nodes.upload(nodes.data(), nodes.size() * sizeof(rrt::DNodeI)));   // after the runs are final
-        HIP_TRY(m.d_leaves.upload(leaves.data(), leaves.size() * sizeof(rrt::DLeaf)));
-        HIP_TRY(m.d_refs.upload(refs.data(), refs.size() * sizeof(int32_t)));
+        HIP_TRY(m.d_refs.upload(refs.data(), refs.size() * sizeof(rrt::DRef)));
         std::vector<rrt::DTri> stream(refs.size());
-        for (size_t j = 0; j < stream.size(); ++j) stream[j] = m.tris[(size_t)refs[j]];
+        for (size_t j = 0; j < stream.size(); ++j) stream[j] = m.tris[(size_t)refs[j].tri];
         {
             // the un-culled leaf loop prefetches up to kStreamPad entries past a leaf: keep them readable
             std::vector<rrt::DTri> padded(stream);
@@ -256,6 +279,17 @@ int commit(rrt_scene* s) {
             grp[g] = u;
         }
         for (size_t g = stream.size() / G; g < grp.size(); ++g) grp[g] = stream.empty() ? rrt::DBox32{} : grp[stream.size() / G - 1];
+        // per leaf: the union of its entries' cull boxes (an empty leaf keeps an inverted box and is skipped by its count)
+        for (rrt::DLeaf& L : leaves) {
+            rrt::DBox32 u{{INFINITY, -INFINITY, INFINITY, -INFINITY, INFINITY, -INFINITY}};
+            for (int32_t k = 0; k < L.count; ++k)
+                for (int a = 0; a < 3; ++a) {
+                    u.v[2 * a] = std::fmin(u.v[2 * a], cull[(size_t)L.first + k].v[2 * a]);
+                    u.v[2 * a + 1] = std::fmax(u.v[2 * a + 1], cull[(size_t)L.first + k].v[2 * a + 1]);
+                }
+            L.content = u;
+        }
+        HIP_TRY(m.d_leaves.upload(leaves.data(), leaves.size() * sizeof(rrt::DLeaf)));
         HIP_TRY(m.d_cull.upload(cull.data(), cull.size() * sizeof(rrt::DBox32)));
         HIP_TRY(m.d_grp.upload(grp.data(), grp.size() * sizeof(rrt::DBox32)));
         dm[i].grp = m.d_grp.as<rrt::DBox32>();
@@ -277,7 +311,7 @@ int commit(rrt_scene* s) {
         dm[i].nodes = m.d_nodes.as<rrt::DNodeI>();
         dm[i].boxes = m.d_boxes.as<rrt::DBox>();
         dm[i].leaves = m.d_leaves.as<rrt::DLeaf>();
-        dm[i].leaf_refs = m.d_refs.as<int32_t>();
+        dm[i].leaf_refs = m.d_refs.as<rrt::DRef>();
         dm[i].tris = m.d_tris.as<rrt::DTri>();
         dm[i].normals = m.d_normals.as<double>();
         dm[i].material = m.material;

@@ -19,7 +19,7 @@ constexpr int kMaxLevels = 18;  // max_bounce + 2 casts per path, max_bounce <= 
 //                       (ufo: 27 KB) to be staged whole in LDS by the trace kernels.
 //   DBox[node]    48 B  every node's box: find_point tests the box of the node it starts from,
 //                       and rope targets may be interior nodes (kdtree.rs:23-24, 139-161).
-//   DLeaf[leaf]   80 B  box again (exit test + get_plane), ropes, range in the triangle stream.
+//   DLeaf[leaf]  128 B  box again (exit test + get_plane), ropes, range in the triangle stream, content box.
 struct DNodeI {
     union {
         double split;    // interior node
@@ -35,14 +35,22 @@ struct DBox {
     double mx[3];
 };
 
-struct DLeaf {
+struct DBox32 {
+    float v[6];   // mn.x, mx.x, mn.y, mx.y, mn.z, mx.z  (axis pairs, as the packed-f32 slab test reads them)
+};
+
+// One 128-byte line per leaf: everything a visit reads -- the content box on arrival, box + ropes on the way out.
+struct alignas(128) DLeaf {
     double mn[3];
     double mx[3];
     int32_t rope[6];   // node index or -1; 0..2 = -x,-y,-z faces, 3..5 = +x,+y,+z
     int32_t first;     // first entry in the triangle stream (multiple of kGroup)
     int32_t count;
+    DBox32 content;    // union of the cull boxes of the leaf's entries (meshes; unused in a Scene<T> group's tree):
+                       // a ray that misses it cannot be accepted by any triangle of the leaf
+    int32_t pad[6];
 };
-static_assert(sizeof(DLeaf) == 80, "DLeaf layout");
+static_assert(sizeof(DLeaf) == 128 && offsetof(DLeaf, content) == 80, "DLeaf layout");
 
 // Per triangle: v0, e1 = v1 - v0, e2 = v2 - v0 (the two subtractions of
 // triangle.rs:30-31 hoisted to scene build; same IEEE results), 72 bytes.
@@ -52,17 +60,22 @@ struct DTri {
     double e2[3];
 };
 
-// f32 bounding box of one triangle-stream entry, rounded outward (cull test only).
-struct DBox32 {
-    float v[6];   // mn.x, mx.x, mn.y, mx.y, mn.z, mx.z  (axis pairs, as the packed-f32 slab test reads them)
+// DBox32 (above): f32 bounding box of one triangle-stream entry, rounded outward (cull test only).
+
+// Inside a leaf the stream is spatially sorted (Morton order of the triangles' centroids), so that the union box
+// of four consecutive entries is tight; the reference walks the leaf in ITS list order and keeps the first of equally
+// distant hits (kdtree.rs:207, strict <), so that position travels with the entry and decides ties.
+struct DRef {
+    int32_t tri;     // triangle id (index into Model.triangles)
+    int32_t rank;    // position in the reference's leaf list
 };
 
 struct DMesh {
     const DNodeI* nodes;
     const DBox* boxes;
     const DLeaf* leaves;
-    const int32_t* leaf_refs;   // triangle id of stream entry j
-    const DTri* tris;           // leaf-ordered stream: entry j = the triangle leaf_refs[j] (duplicated per
+    const DRef* leaf_refs;      // stream entry j: its triangle id and its position in the reference's leaf list
+    const DTri* tris;           // leaf-ordered stream: entry j = the triangle leaf_refs[j].tri (duplicated per
                                 // leaf, so a leaf's triangles are contiguous and the next one can be prefetched)
     const double* normals;  // 3 per triangle (indexed by triangle id)
     const DBox32* cull;     // per stream entry, see "conservative cull" in rrt_kernels.hip

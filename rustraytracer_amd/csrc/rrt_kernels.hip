@@ -384,12 +384,17 @@ struct LeafBest {
 };
 
 // One Triangle::collide + the closest-in-leaf bookkeeping of kdtree.rs:203-212.
-RRT_DEV void leaf_test(const TriData& T, int32_t entry, V3 o, V3 d, LeafBest* b) {
+// The stream inside a leaf is not in the reference's list order (see DRef): of equally distant hits the one that
+// comes first in THAT order wins (kdtree.rs:207 is a strict <), decided by the entries' ranks -- a load that only
+// ever happens on an exact tie.
+RRT_DEV void leaf_test(const TriData& T, int32_t entry, const RRT_GLOBAL DRef* refs, V3 o, V3 d, LeafBest* b) {
     double t;
     if (tri_collide(T, o, d, &t)) {
         const V3 pos = o + d * t;                 // triangle.rs:53
         const double dist = mag2(pos - o);        // kdtree.rs:206
-        if (dist < b->dist) {
+        bool better = dist < b->dist;
+        if (dist == b->dist && b->entry >= 0) better = refs[entry].rank < refs[b->entry].rank;
+        if (better) {
             b->dist = dist; b->t = t; b->entry = entry;
         }
     }
@@ -419,14 +424,50 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
     if (CULL != 0) cr = make_cull_ray(K, o, d, inv);
     const RRT_GLOBAL DLeaf* leaves = as_global(M.leaves);
     const RRT_GLOBAL DTri* stream = as_global(M.tris);
+    const RRT_GLOBAL DRef* refs = as_global(M.leaf_refs);
     uint32_t visits = 0;
-    while (lr.leaf >= 0) {
-        if (++visits > kMaxLeafVisits) {
-            atomicAdd(&stats[1], 1ull);
-            return;
-        }
-        const RRT_GLOBAL DLeaf* L = leaves + lr.leaf;
-        CNT(4);
+    // "While-while": the inner loop walks on through leaves in which this ray provably finds nothing (empty, or the
+    // ray misses the leaf's content box -- the union of its entries' cull boxes, so every entry would be culled) and
+    // only the leaves that pass get the three test phases below.  Written as "if (content) test" inside one loop, a
+    // wave paid the phases on every trip in which ANY of its lanes had content (cfg5: nearly always, for a third of
+    // the lanes); here it pays them once per leaf-with-content of its busiest lane.
+    bool advance = false;
+    for (;;) {
+        const RRT_GLOBAL DLeaf* L;
+        bool content;
+        do {
+            if (advance) {
+                CNT(7);
+                // the six ropes travel with the box (one round trip); the face picks among registers
+                typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
+                typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+                static_assert(sizeof(DLeaf) % 16 == 0 && offsetof(DLeaf, rope) % 16 == 0, "ropes are fetched as 16 + 8 bytes");
+                L = leaves + lr.leaf;
+                const V3 mn = ld3g(L->mn), mx = ld3g(L->mx);
+                const i32x4 r03 = *(const RRT_GLOBAL i32x4*)&L->rope[0];
+                const i32x2 r45 = *(const RRT_GLOBAL i32x2*)&L->rope[4];
+                if (M.flags & kTreeStaleBoxes) point = leaf_exit_general(mn, mx, point, d, inv) + d * 0.001;
+                else point = box_exit(mn, mx, point, d, inv) + d * 0.001;
+                const int pl = get_plane(point, mn, mx);
+                const int32_t nb = pl == 0 ? r03.x : pl == 1 ? r03.y : pl == 2 ? r03.z : pl == 3 ? r03.w : pl == 4 ? r45.x : r45.y;
+                if (nb < 0) return;
+                lr = find_point(M.nodes, M.boxes, lnodes, nb, point);
+            }
+            advance = true;
+            if (lr.leaf < 0) return;
+            if (++visits > kMaxLeafVisits) {
+                atomicAdd(&stats[1], 1ull);
+                return;
+            }
+            CNT(4);
+            L = leaves + lr.leaf;
+            content = lr.count > 0;
+            if (CULL == 1 && content) content = cull_keep(ld_box32(&L->content), cr);
+        } while (!content);
+        CNT(9);   // leaves with content (probe build; shares the slot of shade_direct, which cfg5 probes ignore)
+        bool content_keep = true;
+        if (CULL == 2) content_keep = cull_keep(ld_box32(&L->content), cr);
+        (void)content_keep;
         const int32_t first = lr.first, count = lr.count;
         LeafBest best;
         best.dist = kF64Max; best.t = 0.0; best.entry = -1;
@@ -439,9 +480,9 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
             TriData A = ld_tri(tp);
             for (int32_t k = 0; k < count; k += 2) {
                 const TriData B = ld_tri(tp + k + 1);
-                leaf_test(A, first + k, o, d, &best);
+                leaf_test(A, first + k, refs, o, d, &best);
                 A = ld_tri(tp + k + 2);
-                if (k + 1 < count) leaf_test(B, first + k + 1, o, d, &best);
+                if (k + 1 < count) leaf_test(B, first + k + 1, refs, o, d, &best);
                 if (ANY && best.dist < lim2) break;
             }
         } else {
@@ -483,6 +524,7 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
                 }
                 const uint32_t valid = n >= 32 ? 0xffffffffu : ((1u << n) - 1u);
                 keep &= valid;
+                if (CULL == 2 && !content_keep) keep = 0u;   // mode 1 would have walked past this leaf
                 uint32_t todo = (CULL == 2) ? valid : keep;   // verify mode runs every entry
                 while (todo != 0u) {
                     CNT(6);
@@ -494,7 +536,7 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
                         double t;
                         if (tri_collide(T, o, d, &t)) atomicAdd(&stats[2], 1ull);
                     }
-                    leaf_test(T, first + e, o, d, &best);
+                    leaf_test(T, first + e, refs, o, d, &best);
                     if (ANY && best.dist < lim2) break;
                 }
                 if (ANY && best.dist < lim2) break;
@@ -504,20 +546,6 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
             *out = best;
             return;
         }
-        CNT(7);
-        // the six ropes travel with the box (one round trip); the face picks among registers
-        typedef int32_t i32x2 __attribute__((ext_vector_type(2)));
-        typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-        static_assert(sizeof(DLeaf) % 16 == 0 && offsetof(DLeaf, rope) % 16 == 0, "ropes are fetched as 16 + 8 bytes");
-        const V3 mn = ld3g(L->mn), mx = ld3g(L->mx);
-        const i32x4 r03 = *(const RRT_GLOBAL i32x4*)&L->rope[0];
-        const i32x2 r45 = *(const RRT_GLOBAL i32x2*)&L->rope[4];
-        if (M.flags & kTreeStaleBoxes) point = leaf_exit_general(mn, mx, point, d, inv) + d * 0.001;
-        else point = box_exit(mn, mx, point, d, inv) + d * 0.001;
-        const int pl = get_plane(point, mn, mx);
-        const int32_t nb = pl == 0 ? r03.x : pl == 1 ? r03.y : pl == 2 ? r03.z : pl == 3 ? r03.w : pl == 4 ? r45.x : r45.y;
-        if (nb < 0) return;
-        lr = find_point(M.nodes, M.boxes, lnodes, nb, point);
     }
 }
 
@@ -808,9 +836,9 @@ RRT_DEV void finish_hit(const DScene& sc, LDS lds, V3 o, V3 d, const Closest& c,
             h->normal = normalize(h->pos - ctr);
             h->mat = lds_field<int32_t>(rec, 8 + offsetof(DSphere, material));
         } else {
-            const int32_t* refs = lds_field<const int32_t*>(rec, 8 + offsetof(DMesh, leaf_refs));
+            const DRef* refs = lds_field<const DRef*>(rec, 8 + offsetof(DMesh, leaf_refs));
             const double* nrm = lds_field<const double*>(rec, 8 + offsetof(DMesh, normals));
-            const int32_t id = as_global(refs)[c.entry];
+            const int32_t id = as_global(refs)[c.entry].tri;
             h->tri = id;
             h->normal = ld3g(as_global(nrm) + 3 * (size_t)id);
             h->mat = lds_field<int32_t>(rec, 8 + offsetof(DMesh, material));
@@ -825,7 +853,7 @@ RRT_DEV void finish_hit(const DScene& sc, LDS lds, V3 o, V3 d, const Closest& c,
             h->mat = S->material;
         } else {
             const DMesh* M = sc.meshes + ent.index;
-            const int32_t id = as_global(M->leaf_refs)[c.entry];
+            const int32_t id = as_global(M->leaf_refs)[c.entry].tri;
             h->tri = id;
             h->normal = ld3g(as_global(M->normals) + 3 * (size_t)id);
             h->mat = M->material;
