@@ -78,7 +78,7 @@ struct HostMesh {
     int material = 0;
     bool stale_boxes = false;        // went through a literal translate: the boxes no longer match the split planes
     // device copies
-    DevBuf d_nodes, d_boxes, d_leaves, d_refs, d_tris, d_normals, d_cull, d_grp;
+    DevBuf d_nodes, d_boxes, d_leaves, d_refs, d_tris, d_normals, d_cull, d_grp, d_top;
 };
 
 // Scene<T> (scene.rs:31-47): kd-tree over member entities
@@ -125,7 +125,7 @@ struct rrt_scene {
     int cull_mode = 1;
 
     bool dirty = true;
-    DevBuf d_ents, d_spheres, d_meshes, d_mats, d_groups, d_plights;
+    DevBuf d_ents, d_spheres, d_meshes, d_mats, d_groups, d_plights, d_mesh_stage;
     rrt::DScene dscene{};
 
     // work buffers
@@ -391,17 +391,67 @@ int commit(rrt_scene* s) {
     // small scenes (the reference's are: 1-4 entities): entity table and materials live in LDS
     d.lds_ents = (!s->ents.empty() && s->ents.size() <= (size_t)rrt::kMaxLdsEnts && s->mats.size() <= (size_t)rrt::kMaxLdsMats) ? 1 : 0;
     d.lds_mats = d.lds_ents ? (int32_t)s->mats.size() : 0;
-    d.lds_mesh = -1;
+    // Which descent arrays the trace kernels keep in LDS: meshes in order, each whole if it still fits the node
+    // budget, else (a tree too large for that) the breadth-first top of its tree; at most kMaxStaged arrays.
+    // RRT_MAX_LDS_NODES / RRT_LDS_TOP_NODES (tests): lower the two limits, so that small meshes take the
+    // large-mesh code paths (0 / 0 = nothing staged: every descent from global memory).
+    int32_t budget = rrt::kMaxLdsNodes, top_nodes = rrt::kTopNodes;
+    if (const char* e = getenv("RRT_MAX_LDS_NODES")) budget = std::min<int32_t>(budget, std::max(0, atoi(e)));
+    if (const char* e = getenv("RRT_LDS_TOP_NODES")) top_nodes = std::min<int32_t>(top_nodes, std::max(0, atoi(e)));
+    d.n_staged = 0;
     d.lds_nodes = 0;
-    // RRT_MAX_LDS_NODES (tests): lower the staging limit, so small meshes take the large-mesh code paths
-    int32_t max_lds_nodes = rrt::kMaxLdsNodes;
-    if (const char* e = getenv("RRT_MAX_LDS_NODES")) max_lds_nodes = std::min<int32_t>(max_lds_nodes, std::max(0, atoi(e)));
-    for (size_t i = 0; i < s->meshes.size(); ++i)
-        if (s->meshes[i]->tree.n_nodes() <= max_lds_nodes) {
-            d.lds_mesh = (int32_t)i;
-            d.lds_nodes = s->meshes[i]->tree.n_nodes();
-            break;
+    std::vector<int32_t> mesh_stage(std::max<size_t>(s->meshes.size(), 1), 0);
+    bool is_top = false;
+    int32_t whole_left = budget, total_left = rrt::kMaxLdsNodes;
+    for (size_t i = 0; i < s->meshes.size() && d.n_staged < rrt::kMaxStaged; ++i) {
+        HostMesh& m = *s->meshes[i];
+        const int32_t nn = m.tree.n_nodes();
+        const int k = d.n_staged;
+        if (nn <= whole_left) {
+            d.st_src[k] = m.d_nodes.as<rrt::DNodeI>();
+            d.st_cnt[k] = nn;
+            is_top = false;
+        } else if (top_nodes >= 3 && top_nodes <= total_left) {
+            // breadth-first top: entry e is interior while both its children 2e+1, 2e+2 are entries too;
+            // otherwise it links to the node of the global pre-order array the descent continues from
+            std::vector<rrt::DNodeI> top((size_t)top_nodes);
+            std::vector<std::pair<int32_t, int32_t>> todo{{0, 0}};      // (entry, node)
+            int32_t used = 0;
+            while (!todo.empty()) {
+                const auto [e, node] = todo.back();
+                todo.pop_back();
+                used = std::max(used, e + 1);
+                rrt::DNodeI& t = top[(size_t)e];
+                if (m.tree.axis[(size_t)node] >= 0 && 2 * e + 2 < top_nodes) {
+                    t.split = m.tree.split[(size_t)node];
+                    t.axis = m.tree.axis[(size_t)node];
+                    t.right = 0;
+                    todo.emplace_back(2 * e + 1, m.tree.child[2 * (size_t)node]);
+                    todo.emplace_back(2 * e + 2, m.tree.child[2 * (size_t)node + 1]);
+                } else {
+                    t.split = 0.0;
+                    t.axis = rrt::kTopLink;
+                    t.right = node;
+                }
+            }
+            top.resize((size_t)used);
+            HIP_TRY(m.d_top.upload(top.data(), top.size() * sizeof(rrt::DNodeI)));
+            d.st_src[k] = m.d_top.as<rrt::DNodeI>();
+            d.st_cnt[k] = used;
+            is_top = true;
+        } else {
+            continue;
         }
+        d.st_off[k] = d.lds_nodes;
+        mesh_stage[i] = is_top ? -(d.lds_nodes + 1) : d.lds_nodes + 1;
+        d.lds_nodes += d.st_cnt[k];
+        if (!is_top) whole_left -= d.st_cnt[k];
+        total_left -= d.st_cnt[k];
+        whole_left = std::min(whole_left, total_left);
+        ++d.n_staged;
+    }
+    HIP_TRY(s->d_mesh_stage.upload(mesh_stage.data(), mesh_stage.size() * sizeof(int32_t)));
+    d.mesh_stage = s->d_mesh_stage.as<int32_t>();
     for (int f = 0; f < 6; ++f) {
         // + 4 readable bytes: the kernels fetch a texel as one unaligned dword (its 3 bytes and the next one)
         HIP_TRY(s->sky[f].d.ensure(s->sky[f].rgb.size() + 4));

@@ -157,8 +157,14 @@ struct DScene {
     const uint8_t* sky[6];   // RGB8 rows
     uint32_t sky_w[6];
     uint32_t sky_h[6];
-    int32_t lds_mesh;        // mesh whose DNodeI array the trace kernels stage in LDS, or -1
-    int32_t lds_nodes;       // its node count (LDS bytes = 16 * lds_nodes)
+    // Descent arrays the trace kernels keep in LDS (stage_scene copies st_cnt[k] nodes from st_src[k] to node
+    // offset st_off[k]): the whole pre-order DNodeI array of every mesh that fits (kind 0), and for a mesh too
+    // large for that the top levels of its tree in breadth-first order (kind 1, see KdTop in rrt_api.cpp).
+    int32_t n_staged;
+    int32_t lds_nodes;       // total nodes staged (LDS bytes = 16 * lds_nodes)
+    int32_t st_off[4], st_cnt[4];
+    const DNodeI* st_src[4];
+    const int32_t* mesh_stage;   // [n_meshes]: +-(LDS node offset + 1), negative for a breadth-first top; 0 = not staged
     int32_t cull_mode;       // 0 = off, 1 = on, 2 = verify (run both, count cull-vs-exact disagreements)
     int32_t lds_ents;        // 1: the trace kernels keep the entity table in LDS (n_ents <= kMaxLdsEnts)
     const DPointLight* plights;   // world.light_sources behind the directional light, in push order
@@ -170,7 +176,10 @@ constexpr int32_t kGroup = 4;            // a leaf's run in the stream starts at
 constexpr int32_t kStreamPad = 4;        // readable entries past the end of DMesh::tris / DMesh::grp
 constexpr int32_t kMaxLdsEnts = 64;      // 128 B of LDS per entity
 constexpr int32_t kMaxLdsMats = 64;      // 72 B of LDS per material
-constexpr int32_t kMaxLdsNodes = 3072;   // 48 KB of LDS per 256-thread block at most
+constexpr int32_t kMaxLdsNodes = 3072;   // 48 KB of LDS per 256-thread block at most, all staged arrays together
+constexpr int32_t kMaxStaged = 4;
+constexpr int32_t kTopNodes = 1023;      // breadth-first top of a large tree: 10 levels, 16 KB
+constexpr int32_t kTopLink = -2;         // DNodeI::axis of a top-array entry that hands over to global node `right`
 
 // Wavefront work buffers for one batch of P paths.  Records are AoS, kRecDoubles f64 (56 B) each:
 //   queue entry  {o.xyz, d.xyz, (u32 path, i32 medium)}   medium = sphere entity the ray travels inside, -1 = none

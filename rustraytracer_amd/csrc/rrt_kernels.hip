@@ -265,10 +265,15 @@ struct LeafRef {
 };
 
 // KDTree::find_point (kdtree.rs:23-33) starting at node `at`.
-// `lnodes` != nullptr: this mesh's descent array is staged in LDS (wave-uniform choice).
+// `lnodes` != nullptr: this mesh's descent array is staged in LDS (wave-uniform choice) -- whole (TOP false), or,
+// for a tree too large for that, only its top levels in breadth-first order (TOP true; only the descent from the
+// root, at == 0, can use it): children of entry i at 2i+1 / 2i+2, an entry with axis kTopLink hands over to node
+// `right` of the global pre-order array, so the first ~10 of the ~20 dependent node loads of a ray's first descent
+// are LDS reads.
+template <bool TOP = false>
 RRT_DEV LeafRef find_point(const DNodeI* nodes, const DBox* boxes, const DNodeI* lnodes, int32_t at, V3 p) {
     const RRT_GLOBAL DBox* bx = as_global(boxes) + at;
-    if (lnodes) {
+    if (!TOP && lnodes) {
         if (!box_contains(ld3g(bx->mn), ld3g(bx->mx), p)) return LeafRef{-1, 0, 0};
         DNodeI n = lnodes[at];
         while (n.axis >= 0) {
@@ -278,11 +283,25 @@ RRT_DEV LeafRef find_point(const DNodeI* nodes, const DBox* boxes, const DNodeI*
         }
         return LeafRef{n.right, n.run[0], n.run[1]};
     }
-    // global-memory descent: the first node is requested together with the box, not after its test
     const RRT_GLOBAL DNodeI* gn = as_global(nodes);
-    double split = gn[at].split;
-    int32_t axis = gn[at].axis, right = gn[at].right;
-    if (!box_contains(ld3g(bx->mn), ld3g(bx->mx), p)) return LeafRef{-1, 0, 0};
+    double split;
+    int32_t axis, right;
+    if (TOP && lnodes) {
+        if (!box_contains(ld3g(bx->mn), ld3g(bx->mx), p)) return LeafRef{-1, 0, 0};
+        uint32_t i = 0;
+        DNodeI n = lnodes[0];
+        while (n.axis >= 0) {
+            CNT(3);
+            i = 2u * i + ((comp(p, n.axis) >= n.split) ? 2u : 1u);
+            n = lnodes[i];
+        }
+        at = n.right;
+        split = gn[at].split; axis = gn[at].axis; right = gn[at].right;
+    } else {
+        // global-memory descent: the first node is requested together with the box, not after its test
+        split = gn[at].split; axis = gn[at].axis; right = gn[at].right;
+        if (!box_contains(ld3g(bx->mn), ld3g(bx->mx), p)) return LeafRef{-1, 0, 0};
+    }
     while (axis >= 0) {
         CNT(3);
         at = (comp(p, axis) >= split) ? right : at + 1;
@@ -407,7 +426,7 @@ RRT_DEV void leaf_test(const TriData& T, int32_t entry, const RRT_GLOBAL DRef* r
 // A leaf whose accepted triangles are all farther still ends the walk (kdtree.rs:214: the first leaf with any hit
 // answers), with out->entry >= 0 and out->dist >= lim2: "hit, but not an occluder".
 template <int CULL, bool ANY = false>
-RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnodes, V3 o, V3 d, LeafBest* out,
+RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnodes, bool ltop, V3 o, V3 d, LeafBest* out,
                           unsigned long long* stats, double lim2 = 0.0) {
     out->entry = -1; out->dist = kF64Max; out->t = 0.0;
     CNT(1);
@@ -419,7 +438,15 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
     }
     CNT(2);
     point = point + d * 0.01;
-    LeafRef lr = find_point(M.nodes, M.boxes, lnodes, 0, point);
+    // `lnodes`: this mesh's staged array -- the whole descent array, or (ltop) only the top of the tree, which
+    // serves the descent from the root; rope targets then descend from global memory
+    LeafRef lr;
+    if (ltop) {
+        lr = find_point<true>(M.nodes, M.boxes, lnodes, 0, point);
+        lnodes = nullptr;
+    } else {
+        lr = find_point(M.nodes, M.boxes, lnodes, 0, point);
+    }
     CullRay cr;
     if (CULL != 0) cr = make_cull_ray(K, o, d, inv);
     const RRT_GLOBAL DLeaf* leaves = as_global(M.leaves);
@@ -590,8 +617,9 @@ struct Closest {
 // ray (entity -> sphere/mesh struct), ~600 cycles a wave cannot overlap with anything: 0.1 ms per
 // entity on a 1080p/16spp frame.  The records are wave-uniform, so they go back into SGPRs.
 #define RRT_LDS __attribute__((address_space(3)))
-constexpr int32_t kEntRec = 32;
-static_assert(sizeof(DSphere) <= 4 * (kEntRec - 2) && sizeof(DMesh) <= 4 * (kEntRec - 2) && sizeof(DGroup) <= 4 * (kEntRec - 2),
+constexpr int32_t kEntRec = 36;        // kind, index, the struct (<= 30 dwords), then for a mesh its mesh_stage word
+constexpr int32_t kEntRecStage = 32;
+static_assert(sizeof(DSphere) <= 4 * (kEntRecStage - 2) && sizeof(DMesh) <= 4 * (kEntRecStage - 2) && sizeof(DGroup) <= 4 * (kEntRecStage - 2),
               "entity record too small");
 // SMALL (kernel template parameter, = DScene::lds_ents): the entity table and the materials are in
 // LDS too.  A compile-time choice, so that the kernels of small scenes carry no global-memory
@@ -600,7 +628,7 @@ template <bool SMALL>
 struct StagedT {
     static constexpr bool kStaged = true;
     static constexpr bool kSmall = SMALL;
-    const DNodeI* nodes;             // descent array of scene.lds_mesh, or nullptr
+    const DNodeI* nodes;             // base of the staged descent arrays (DScene::st_*), or nullptr
     const RRT_LDS uint32_t* ents;    // SMALL: entity records
     const RRT_LDS uint32_t* mats;    // SMALL: the scene's materials (sizeof(DMaterial) each)
     const RRT_LDS double* by255;     // i / 255.0 for i = 0..255 (cubemap.rs:70-74)
@@ -678,8 +706,17 @@ RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LD
             M = sc.meshes[ent.index];
             K = CullConst{{M.center[0], M.center[1], M.center[2]}, M.radius, M.edge_max, M.abs_max};
         }
+        const DNodeI* ln = nullptr;
+        bool ltop = false;
+        if (lnodes) {     // is this mesh's descent array (or its top) among the staged ones?
+            int32_t so;     // +-(LDS node offset + 1), negative = the array is a breadth-first top; 0 = not staged
+            if constexpr (REC) so = __builtin_amdgcn_readfirstlane((int)rec[kEntRecStage]);
+            else so = sc.mesh_stage[ent.index];
+            ltop = so < 0;
+            if (so != 0) ln = lnodes + ((ltop ? -so : so) - 1);
+        }
         LeafBest h;
-        mesh_collide<CULL, ANY>(M, K, ent.index == sc.lds_mesh ? lnodes : nullptr, o, d, &h, stats, lim2);
+        mesh_collide<CULL, ANY>(M, K, ln, ltop, o, d, &h, stats, lim2);
         // same |pos - origin|^2 as the leaf-level metric (kdtree.rs:206 == tracer.rs:184)
         if (h.entry >= 0 && h.dist < best->dist) {
             best->dist = h.dist; best->t = h.t; best->ent = e; best->entry = h.entry;
@@ -1262,36 +1299,37 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
 // Bytes of LDS stage_scene fills (descent array, then entity records); the bounce kernel's unit
 // counter sits right behind them.
 __host__ __device__ inline uint32_t lds_layout_bytes(const DScene& sc) {
-    return (sc.lds_mesh >= 0 ? (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI) : 0u) +
+    return (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI) +
            (sc.lds_ents ? (uint32_t)sc.n_ents * (uint32_t)kEntRec * 4u : 0u) +
            (uint32_t)sc.lds_mats * (uint32_t)sizeof(DMaterial) + 256u * 8u + (uint32_t)kCDoubles * 8u;
 }
 
-// Fills the block's LDS (all threads; ends with a barrier): the descent array of scene.lds_mesh and,
-// after it, the entity records.  Either part may be absent (see DScene::lds_mesh / lds_ents).
+// Fills the block's LDS (all threads; ends with a barrier): the staged descent arrays (DScene::st_*) and,
+// after them, the entity records.  Either part may be absent (see DScene::n_staged / lds_ents).
 template <bool SMALL>
 RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned char* smem, bool with_nodes) {
     StagedT<SMALL> st{nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t off = 0;
-    if (sc.lds_mesh >= 0 && with_nodes) {
-        const DMesh M = sc.meshes[sc.lds_mesh];
+    if (sc.n_staged > 0 && with_nodes) {
         // one 16-byte node per thread and trip, four trips' loads in flight before the first store
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const RRT_GLOBAL u32x4* src = (const RRT_GLOBAL u32x4*)M.nodes;
-        RRT_LDS u32x4* dst = (RRT_LDS u32x4*)smem;
-        const int32_t n = sc.lds_nodes, step = (int32_t)blockDim.x;
-        for (int32_t i = threadIdx.x; i < n; i += 4 * step) {
-            const int32_t i1 = i + step, i2 = i + 2 * step, i3 = i + 3 * step;
-            const u32x4 v0 = src[i];
-            const u32x4 v1 = src[i1 < n ? i1 : i], v2 = src[i2 < n ? i2 : i], v3 = src[i3 < n ? i3 : i];
-            dst[i] = v0;
-            if (i1 < n) dst[i1] = v1;
-            if (i2 < n) dst[i2] = v2;
-            if (i3 < n) dst[i3] = v3;
+        for (int32_t k = 0; k < sc.n_staged; ++k) {
+            const RRT_GLOBAL u32x4* src = (const RRT_GLOBAL u32x4*)sc.st_src[k];
+            RRT_LDS u32x4* dst = (RRT_LDS u32x4*)smem + sc.st_off[k];
+            const int32_t n = sc.st_cnt[k], step = (int32_t)blockDim.x;
+            for (int32_t i = threadIdx.x; i < n; i += 4 * step) {
+                const int32_t i1 = i + step, i2 = i + 2 * step, i3 = i + 3 * step;
+                const u32x4 v0 = src[i];
+                const u32x4 v1 = src[i1 < n ? i1 : i], v2 = src[i2 < n ? i2 : i], v3 = src[i3 < n ? i3 : i];
+                dst[i] = v0;
+                if (i1 < n) dst[i1] = v1;
+                if (i2 < n) dst[i2] = v2;
+                if (i3 < n) dst[i3] = v3;
+            }
         }
         st.nodes = (const DNodeI*)smem;
     }
-    if (sc.lds_mesh >= 0) off = (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI);
+    off = (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI);
     if constexpr (SMALL) {
         RRT_LDS uint32_t* tab = (RRT_LDS uint32_t*)(smem + off);
         for (int32_t i = threadIdx.x; i < sc.n_ents * kEntRec; i += blockDim.x) {
@@ -1306,6 +1344,7 @@ RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned 
             if (w == 0) v = (uint32_t)ent.kind;
             else if (w == 1) v = (uint32_t)ent.index;
             else if (w - 2 < n) v = src[w - 2];
+            else if (kind == 1 && w == kEntRecStage) v = (uint32_t)sc.mesh_stage[ent.index];
             tab[i] = v;
         }
         st.ents = tab;

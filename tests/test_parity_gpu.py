@@ -465,11 +465,15 @@ def test_large_entity_count_takes_the_global_memory_kernels(H, O, scenes):
         assert len(np.unique(go["ids"][..., 0])) > 50
 
 
-def test_large_mesh_paths_on_small_meshes(H, O, scenes, monkeypatch):
-    """RRT_MAX_LDS_NODES=0 makes every mesh take the code paths of meshes too large for the LDS descent array
-    (descent array read from global memory inside the wavefront kernels instead of LDS).  Same results, bit
-    for bit: main.rs scene with jitter, the diffuse-bounce UFO, incoherent rays, cull modes 1 and 2."""
+@pytest.mark.parametrize("top_nodes", [0, 63, 1023])
+def test_large_mesh_paths_on_small_meshes(H, O, scenes, monkeypatch, top_nodes):
+    """RRT_MAX_LDS_NODES=0 makes every mesh take the code paths of meshes too large for a whole descent array in
+    LDS: with RRT_LDS_TOP_NODES=0 every descent runs from global memory; with 63 / 1023 the top 5 / 9+ levels of
+    each tree are staged in breadth-first order and the descent from the root is split between LDS and global
+    memory (what the 2 M-triangle config does).  Same results, bit for bit: main.rs scene with jitter, the
+    diffuse-bounce UFO, incoherent rays, a 63-entity world (two meshes staged), cull modes 1 and 2."""
     monkeypatch.setenv("RRT_MAX_LDS_NODES", "0")
+    monkeypatch.setenv("RRT_LDS_TOP_NODES", str(top_nodes))
     g, c = scenes.main_rs_scene(H.World(device=0), H.loaders), scenes.main_rs_scene(O.OracleScene(), O)
     for mode in (1, 2):
         g.set_cull_mode(mode)
