@@ -264,6 +264,9 @@ def main():
 
     frame = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
     pipe = D.TilePipeline(scene, w, h, world, dev, frame) if world > 1 else None
+    if world > 1:
+        scene.set_timing(0)      # no hipEvents between the launches of a rank's sub-millisecond frames (N = 1 keeps them:
+                                 # the roofline needs the primary kernel's live duration)
 
     def sync():
         if world > 1:
@@ -361,6 +364,7 @@ def main():
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t0) / n * 1e3)
             return median(ts[1:])
+        scene.set_timing(0)      # as the N-rank path runs it
         t_full = frame_ms(0, 1, frame.data_ptr())
         local, _g = D.alloc_tile_buffers(w, h, 8, dev)
         t_rank = [frame_ms(r, 8, local.data_ptr()) for r in range(8)]
@@ -369,6 +373,7 @@ def main():
                       "what": "T(full)/8 over max_r T(rank r of 8), each measured alone on this one GPU, host-timed with a "
                               "device sync around 10 frames; excludes the RCCL gather (0.78 MB per rank)"}
         # leave the work buffers sized for the bench frame again
+        scene.set_timing(2)
         st = Hst.make_settings(w, h, spp=spp0, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune, batch_spp=args.batch_spp)
         scene.render_device(st, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()

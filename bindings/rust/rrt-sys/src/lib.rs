@@ -89,6 +89,7 @@ extern "C" {
     pub fn rrt_set_ambient(s: *mut rrt_scene, ambient: f64) -> c_int;
     pub fn rrt_set_work_budget(s: *mut rrt_scene, bytes: u64) -> c_int;
     pub fn rrt_set_cull_mode(s: *mut rrt_scene, mode: c_int) -> c_int;
+    pub fn rrt_set_timing(s: *mut rrt_scene, level: c_int) -> c_int;
     pub fn rrt_scene_commit(s: *mut rrt_scene) -> c_int;
 
     pub fn rrt_render(s: *mut rrt_scene, cam: *const rrt_camera, st: *const rrt_settings, out_rgb8: *mut u8,
@@ -100,6 +101,7 @@ extern "C" {
                                      d_rgb8: *mut c_void, d_ids: *mut c_void, d_t: *mut c_void, d_color: *mut c_void,
                                      stream: *mut c_void) -> c_int;
     pub fn rrt_noalloc_scratch_bytes() -> u64;
+    pub fn rrt_tile_skew(width: u32, tile_world: u32) -> u32;
     pub fn rrt_tile_slots(width: u32, height: u32, tile_world: u32) -> i64;
     pub fn rrt_assemble_tiles(d_gathered: *const c_void, width: u32, height: u32, tile_world: u32,
                               d_rgb8: *mut c_void, stream: *mut c_void) -> c_int;

@@ -60,9 +60,12 @@ typedef struct rrt_camera {
  *                reflection ray is spawned while ray.bounce <= max_bounce.
  *   prune_zero_mix  1 = do not trace reflection rays whose mix is exactly 0.0
  *                (value-identical; changes the ray count).
- *   tile_rank/tile_world  image-tile sharding: 32x8-pixel tiles, tile t (row
- *                major over the tile grid) belongs to rank t % tile_world.
- *                tile_world = 1 renders the whole frame.
+ *   tile_rank/tile_world  image-tile sharding: 32x8-pixel tiles; tile t belongs
+ *                to rank t % tile_world and sits in row ty = t / tiles_x of the
+ *                tile grid, column (t % tiles_x + rrt_tile_skew() * ty) % tiles_x
+ *                (each row of tiles rotated, so that neighbouring tiles of a row
+ *                AND of a column go to different ranks).  tile_world = 1 renders
+ *                the whole frame.
  *   batch_spp    samples per pixel per wavefront batch; 0 = choose from the
  *                work-memory budget (rrt_set_work_budget). */
 typedef struct rrt_settings {
@@ -218,6 +221,13 @@ int rrt_set_work_budget(rrt_scene* s, uint64_t bytes);
  * disagreements in rrt_stats.cull_violations). */
 int rrt_set_cull_mode(rrt_scene* s, int mode);
 
+/* hipEvents a render records for rrt_get_stats (no reference counterpart; the reference times the whole
+ * render with one Instant, tracer.rs:79,173): 2 (default) = frame begin/end and a pair around the primary
+ * kernel and around the bounce kernels of every batch; 1 = frame begin/end only; 0 = none (the *_ms fields
+ * of rrt_stats stay 0).  An event between two launches idles the GPU for ~3 us: a caller that renders
+ * sub-millisecond frames back to back (one rank of a tile-sharded frame) turns them off. */
+int rrt_set_timing(rrt_scene* s, int level);
+
 /* Uploads the scene to the device (idempotent; render calls it if needed). */
 int rrt_scene_commit(rrt_scene* s);
 
@@ -256,6 +266,9 @@ int rrt_render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* s
 int rrt_render_device_noalloc(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids,
                               void* d_t, void* d_color, void* stream);
 uint64_t rrt_noalloc_scratch_bytes(void);
+
+/* The per-row rotation of the tile grid used for tile_world ranks (0 for one rank), see rrt_settings. */
+uint32_t rrt_tile_skew(uint32_t width, uint32_t tile_world);
 
 /* Tiles each rank owns (padded to equal size so the gather is regular). */
 int64_t rrt_tile_slots(uint32_t width, uint32_t height, uint32_t tile_world);

@@ -42,9 +42,9 @@ EXPORTS = [
     "rrt_default_camera", "rrt_default_settings", "rrt_scene_create", "rrt_scene_destroy",
     "rrt_add_material", "rrt_add_material_ext", "rrt_add_sphere", "rrt_add_mesh", "rrt_add_group", "rrt_set_sky_face",
     "rrt_set_directional_light", "rrt_set_ambient", "rrt_add_point_light", "rrt_set_shadow_mode", "rrt_translate_entity",
-    "rrt_occluded_rays", "rrt_set_work_budget", "rrt_set_cull_mode",
+    "rrt_occluded_rays", "rrt_set_work_budget", "rrt_set_cull_mode", "rrt_set_timing",
     "rrt_scene_commit",
-    "rrt_render", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_assemble_tiles",
+    "rrt_render", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_tile_skew", "rrt_assemble_tiles",
     "rrt_trace_rays", "rrt_cast_rays", "rrt_get_stats", "rrt_mesh_tree_sizes",
     "rrt_mesh_tree_export", "rrt_selftest_math", "rrt_philox4x32_10",
     "rrt_host_load_model", "rrt_host_add_model", "rrt_host_load_png_rgb8",
@@ -93,11 +93,14 @@ def _load():
     L.rrt_occluded_rays.argtypes = [vp, vp, vp, i64, vp]
     L.rrt_set_work_budget.argtypes = [vp, u64]
     L.rrt_set_cull_mode.argtypes = [vp, i32]
+    L.rrt_set_timing.argtypes = [vp, i32]
     L.rrt_scene_commit.argtypes = [vp]
     L.rrt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp]
     L.rrt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp, vp]
     L.rrt_render_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp, vp]
     L.rrt_noalloc_scratch_bytes.restype = u64
+    L.rrt_tile_skew.argtypes = [u32, u32]
+    L.rrt_tile_skew.restype = u32
     L.rrt_tile_slots.argtypes = [u32, u32, u32]
     L.rrt_tile_slots.restype = i64
     L.rrt_assemble_tiles.argtypes = [vp, u32, u32, u32, vp, vp]

@@ -123,6 +123,7 @@ struct rrt_scene {
     double ambient = 0.15;  // tracer.rs:73
     uint64_t work_budget = 16ull << 30;
     int cull_mode = 1;
+    int timing = 2;        // rrt_set_timing: 0 no events, 1 frame begin/end, 2 + per-kernel pairs
 
     bool dirty = true;
     DevBuf d_ents, d_spheres, d_meshes, d_mats, d_groups, d_plights, d_mesh_stage;
@@ -508,6 +509,7 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
     fr.tiles_x = (st->width + RRT_TILE_W - 1) / RRT_TILE_W;
     fr.tiles_y = (st->height + RRT_TILE_H - 1) / RRT_TILE_H;
     const uint64_t n_tiles = (uint64_t)fr.tiles_x * fr.tiles_y;
+    fr.tile_skew = rrt::tile_skew(fr.tiles_x, st->tile_world);
     fr.n_slots = (uint32_t)((n_tiles + st->tile_world - 1) / st->tile_world);
     fr.npx_local = fr.n_slots * 256u;
     out->levels = st->max_bounce + 2;
@@ -529,7 +531,7 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
     for (uint32_t slot = 0; slot < fr.n_slots; ++slot) {
         const uint64_t tile = (uint64_t)slot * st->tile_world + st->tile_rank;
         if (tile >= n_tiles) continue;
-        const uint32_t tx = (uint32_t)(tile % fr.tiles_x), ty = (uint32_t)(tile / fr.tiles_x);
+        const uint32_t ty = (uint32_t)(tile / fr.tiles_x), tx = (uint32_t)((tile % fr.tiles_x + (uint64_t)fr.tile_skew * ty) % fr.tiles_x);
         const uint32_t w = std::min<uint32_t>(RRT_TILE_W, st->width - tx * RRT_TILE_W);
         const uint32_t h = std::min<uint32_t>(RRT_TILE_H, st->height - ty * RRT_TILE_H);
         valid += (uint64_t)w * h;
@@ -638,14 +640,15 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         if (rc) return rc;
     }
     hipStream_t stream = (hipStream_t)stream_v;
-    if (!NOALLOC && !s->ev_begin) {
+    const bool timed = !NOALLOC && s->timing >= 1, timed_kernels = !NOALLOC && s->timing >= 2;
+    if (timed && !s->ev_begin) {
         HIP_TRY(hipEventCreate(&s->ev_begin));
         HIP_TRY(hipEventCreate(&s->ev_end));
     }
     s->timed_used = 0;
-    s->frame_timed = !NOALLOC;
+    s->frame_timed = timed;
     s->stats_src = wk.stats;
-    if (!NOALLOC) HIP_TRY(hipEventRecord(s->ev_begin, stream));
+    if (timed) HIP_TRY(hipEventRecord(s->ev_begin, stream));
     HIP_TRY(hipMemsetAsync(wk.stats, 0, 8 * 8, stream));
     rrt::DFrame fr = pl.fr;
     for (uint32_t b = 0; b < pl.n_batches; ++b) {
@@ -653,7 +656,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         fr.ns = std::min(pl.batch_spp, st->spp - fr.s0);
         HIP_TRY(hipMemsetAsync(wk.q_count, 0, 2 * (rrt::kMaxLevels + 1) * 4, stream));
         TimedLaunch* tl = nullptr;
-        if (!NOALLOC) {
+        if (timed_kernels) {
             rc = timed_slot(s, &tl);
             if (rc) return rc;
             tl->primary = true;
@@ -661,7 +664,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
             HIP_TRY(hipEventRecord(tl->a, stream));
         }
         rrt::launch_primary(s->dscene, wk, fr, (int32_t*)d_ids, (double*)d_t, stream);
-        if (!NOALLOC) {
+        if (timed_kernels) {
             HIP_TRY(hipEventRecord(tl->b, stream));
             // one event pair around the batch's bounce levels together (each hipEventRecord between two
             // launches costs ~3 us of idle GPU: ten events a frame were 1.5 % of it)
@@ -673,10 +676,10 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         }
         for (uint32_t bounce = 1; bounce <= st->max_bounce + 1; ++bounce)
             rrt::launch_bounce(s->dscene, wk, fr, bounce, stream);
-        if (!NOALLOC) HIP_TRY(hipEventRecord(tl->b, stream));
+        if (timed_kernels) HIP_TRY(hipEventRecord(tl->b, stream));
         rrt::launch_accumulate(wk, fr, b + 1 == pl.n_batches, (uint8_t*)d_rgb8, (double*)d_color, stream);   // the last one resolves
     }
-    if (!NOALLOC) HIP_TRY(hipEventRecord(s->ev_end, stream));
+    if (timed) HIP_TRY(hipEventRecord(s->ev_end, stream));
     HIP_TRY(hipGetLastError());
     s->have_frame = true;
     s->stats = rrt_stats{};
@@ -962,6 +965,12 @@ int rrt_set_work_budget(rrt_scene* s, uint64_t bytes) {
     return RRT_OK;
 }
 
+int rrt_set_timing(rrt_scene* s, int level) {
+    if (!s || level < 0 || level > 2) return fail(RRT_E_INVALID, "timing level must be 0, 1 or 2");
+    s->timing = level;
+    return RRT_OK;
+}
+
 int rrt_set_cull_mode(rrt_scene* s, int mode) {
     if (!s || mode < 0 || mode > 2) return fail(RRT_E_INVALID, "cull mode must be 0, 1 or 2");
     s->cull_mode = mode;
@@ -974,6 +983,10 @@ int rrt_scene_commit(rrt_scene* s) try {
     return commit(s);
 } catch (...) {
     return on_exception();
+}
+
+uint32_t rrt_tile_skew(uint32_t width, uint32_t tile_world) {
+    return rrt::tile_skew((width + RRT_TILE_W - 1) / RRT_TILE_W, tile_world);
 }
 
 int64_t rrt_tile_slots(uint32_t width, uint32_t height, uint32_t tile_world) {

@@ -1168,17 +1168,26 @@ RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y
     const uint32_t slot = lp >> 8, in = lp & 255u;
     const uint32_t tile = slot * fr.tile_world + fr.tile_rank;
     if (tile >= fr.tiles_x * fr.tiles_y) return false;
-    const uint32_t tx = tile % fr.tiles_x, ty = tile / fr.tiles_x;
+    const uint32_t ty = tile / fr.tiles_x, tx = (tile - ty * fr.tiles_x + fr.tile_skew * ty) % fr.tiles_x;
     *x = tx * RRT_TILE_W + (in & 31u);
     *y = ty * RRT_TILE_H + (in >> 5);
     return *x < fr.width && *y < fr.height;
 }
 
 // One cast() (tracer.rs:177-211) of path `path` at depth `bounce`.
+// What a cast leaves for the next level when the bounce kernel runs in tail mode (the lane carries on itself).
+struct NextRay {
+    V3 o, d;
+    int32_t medium;
+    bool cont, zero_mix;
+};
+
+// `next` != nullptr (bounce kernel, tail mode): the continuation ray is handed back instead of being queued.
 template <bool PRIMARY, int CULL, bool GROUPS, bool PL, class LDS>
 RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFrame& fr, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
-                         uint32_t pixel, uint32_t sample, bool dead_sky = false, unsigned long long* tacc = nullptr) {
+                         uint32_t pixel, uint32_t sample, bool dead_sky = false, unsigned long long* tacc = nullptr,
+                         NextRay* next = nullptr) {
     const uint64_t P = wk.cap;
     const uint32_t rec_off = path * (uint32_t)(kRecDoubles * 8);
     const bool aov = sample == 0u;
@@ -1282,6 +1291,10 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
     // next level is then all live or all dead.  In one mixed queue the units were mixed too (waves of UFO
     // tiles and of sphere tiles append at the same time), and a unit costs what its dearest lane costs:
     // measured 10.7 k cycles for an all-dead unit against 43 k for one with live rays in it.
+    if (!PRIMARY && next) {
+        next->o = ro; next->d = rd; next->medium = medium; next->cont = cont; next->zero_mix = zero_mix;
+        return;
+    }
     const uint32_t slot_live = queue_slot(&wk.q_count[bounce + 1], cont && !zero_mix);
     const uint32_t slot_dead = queue_slot(&wk.q_count[kMaxLevels + 1 + bounce + 1], cont && zero_mix);
     if (cont) {
@@ -1422,7 +1435,9 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         const uint32_t path = chunk * 256u + threadIdx.x;
         const uint32_t s_local = chunk / n_tiles, slot = chunk - s_local * n_tiles;
         const uint32_t tile = slot * fr.tile_world + fr.tile_rank;
-        const uint32_t ty = tile / fr.tiles_x, tx = tile - ty * fr.tiles_x;
+        const uint32_t ty = tile / fr.tiles_x;
+        uint32_t tx = tile - ty * fr.tiles_x;
+        if (fr.tile_skew) tx = (tx + fr.tile_skew * ty) % fr.tiles_x;      // wave-uniform: scalar arithmetic
         const uint32_t x = tx * RRT_TILE_W + (my_in & 31u), y = ty * RRT_TILE_H + (my_in >> 5);
         const bool active = tile < fr.tiles_x * fr.tiles_y && x < fr.width && y < fr.height;
         const uint32_t sample = fr.s0 + s_local;
@@ -1431,6 +1446,10 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         process_ray<true, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample);
     }
 }
+
+// A bounce level with at most this many rays runs in tail mode (see k_wave_bounce): fewer rays than the chip has
+// wave slots for (256 CUs x 16 waves x 64 lanes = 262 144), so re-queueing them level by level only adds launches.
+constexpr uint32_t kTailRays = 1u << 16;
 
 // Bounce level `bounce`: the queue is cut into units of 64 rays; block b owns units b, b + grid, ...
 // and its four waves pull them from a counter in LDS.  Rays of a bounce level differ in cost by
@@ -1447,6 +1466,7 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     }
     const uint32_t live_units = (n_live + 63u) >> 6, n_units = live_units + ((n_dead + 63u) >> 6);
     if (blockIdx.x >= n_units) return;          // whole block idle (block-uniform): skip the staging too
+    const bool tail = count <= kTailRays;       // grid-uniform: every block reads the same two counters
     const uint32_t my_units = (n_units - blockIdx.x + gridDim.x - 1u) / gridDim.x;
     RRT_LDS uint32_t* next_unit = (RRT_LDS uint32_t*)(smem + lds_layout_bytes(sc));
     if (threadIdx.x == 0) *next_unit = 0u;
@@ -1487,6 +1507,27 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
         }
         const unsigned long long t1 = TSTAMP();
         unsigned long long tch = 0;
+        if (tail) {
+            // Thin level: nothing is gained by queueing its few continuation rays for another launch (a launch whose
+            // rays do not fill the chip lasts as long as its slowest ray: 25-90 us each for the last levels of a
+            // frame).  Each lane carries its own path on to the end; the launches of the deeper levels find their
+            // queues empty.  All lanes of the wave sit at the same depth, so the level stays wave-uniform.
+            bool act = active;
+            for (uint32_t b = bounce;;) {
+                NextRay nx;
+                process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, act, path, o, d, medium, b, nullptr, nullptr, 0u, 0u, dead_sky, &tch, &nx);
+                act = act && nx.cont;
+                const unsigned long long going = __ballot(act);
+                if (going == 0ull) break;
+                ++b;
+                if (lane == (uint32_t)(__ffsll((long long)going) - 1)) {      // the rays of level b, counted where they are cast
+                    const unsigned long long n = (unsigned long long)__popcll(going);
+                    atomicAdd(&wk.stats[0], n);
+                    if (b < 4u) atomicAdd(&wk.stats[4 + b], n);
+                }
+                o = nx.o; d = nx.d; medium = nx.medium; dead_sky = nx.zero_mix;
+            }
+        } else
         process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, dead_sky, &tch);
         const unsigned long long t2 = TSTAMP();
         if (__ballot(active && !dead_sky) != 0ull) acc_lc += tch;
@@ -1560,11 +1601,12 @@ __global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr, uint8_t
 
 // [world][slots][8][32][3] -> row-major [H][W][3]
 __global__ __launch_bounds__(256) void k_assemble(const uint8_t* g, uint32_t w, uint32_t h, uint32_t world,
-                                                  uint32_t slots, uint32_t tiles_x, uint8_t* out) {
+                                                  uint32_t slots, uint32_t tiles_x, uint32_t skew, uint8_t* out) {
     const uint32_t px = blockIdx.x * 256u + threadIdx.x;
     if (px >= w * h) return;
     const uint32_t x = px % w, y = px / w;
-    const uint32_t tile = (y / RRT_TILE_H) * tiles_x + (x / RRT_TILE_W);
+    const uint32_t ty = y / RRT_TILE_H, txp = x / RRT_TILE_W;
+    const uint32_t tile = ty * tiles_x + (txp + tiles_x - (skew * ty) % tiles_x) % tiles_x;     // undo the row rotation
     const uint32_t rank = tile % world, slot = tile / world;
     const size_t src = (((size_t)rank * slots + slot) * 256u + (y % RRT_TILE_H) * RRT_TILE_W + (x % RRT_TILE_W)) * 3;
     out[3 * (size_t)px] = g[src]; out[3 * (size_t)px + 1] = g[src + 1]; out[3 * (size_t)px + 2] = g[src + 2];
@@ -1698,8 +1740,15 @@ inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) 
     }()
 
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
+    // about eight 256-path chunks per persistent block (the per-block LDS staging is then ~3 % of its work; measured
+    // on the full cfg2 frame, 130 k chunks: 4096 blocks 1.63 ms, 8192 1.51, 16384 1.47, 32768 1.51), a multiple of 8
+    // for the XCD-aware order, at least 2048 blocks so that a small launch still fills the chip
     const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
-    const uint32_t grid = (uint32_t)(chunks < trace_grid() ? chunks : trace_grid());
+    uint64_t want = (chunks / 8 + 2047) / 2048 * 2048;      // in steps of 2048 blocks = two rounds of resident blocks
+    if (want > chunks) want = chunks;
+    if (want > trace_grid()) want = trace_grid();
+    if (want >= 8) want -= want % 8;
+    const uint32_t grid = (uint32_t)(want ? want : 1);
     auto k = RRT_PICK(k_wave_primary);
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, d_ids, d_t);
 }
@@ -1716,7 +1765,7 @@ void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t
     const uint32_t slots = (tiles_x * tiles_y + world - 1) / world;
     const uint32_t n = w * h;
     hipLaunchKernelGGL(k_assemble, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_gathered, w, h, world,
-                       slots, tiles_x, d_rgb8);
+                       slots, tiles_x, tile_skew(tiles_x, world), d_rgb8);
 }
 void launch_trace_rays(const DScene& sc, const double* d_rays, int64_t n, int32_t* ent, int32_t* tri, double* t,
                        double* pos, double* nrm, unsigned long long* stats, void* stream) {

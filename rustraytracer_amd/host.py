@@ -153,6 +153,9 @@ class World:
     def set_cull_mode(self, mode):
         B.check(B.lib.rrt_set_cull_mode(self.h, int(mode)))
 
+    def set_timing(self, level):
+        B.check(B.lib.rrt_set_timing(self.h, int(level)))
+
     def commit(self):
         B.check(B.lib.rrt_scene_commit(self.h))
 

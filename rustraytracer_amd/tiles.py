@@ -16,9 +16,25 @@ def tile_slots(width, height, world):
     return (tx * ty + world - 1) // world
 
 
+def tile_skew(tiles_x, world):
+    """Mirror of rrt::tile_skew (csrc/rrt_device.h): row ty of the tile grid is rotated by skew * ty columns, so
+    that the rank stride down a column of tiles is coprime to the world size (near 0.38 of it)."""
+    if world <= 1 or tiles_x == 0:
+        return 0
+    from math import gcd
+    best = min((g for g in range(1, world) if gcd(g, world) == 1), key=lambda g: (abs(g - 0.382 * world), g))
+    return (tiles_x % world + world - best) % world
+
+
 def owner_of_tile(tile, world):
-    """(rank, slot) of tile index `tile` (row-major over the tile grid)."""
+    """(rank, slot) of tile index `tile`."""
     return tile % world, tile // world
+
+
+def tile_origin(tile, tiles_x, world):
+    """Pixel origin (x0, y0) of tile index `tile`: row tile // tiles_x, column rotated by the row's skew."""
+    ty = tile // tiles_x
+    return ((tile % tiles_x + tile_skew(tiles_x, world) * ty) % tiles_x) * TILE_W, ty * TILE_H
 
 
 def extract_rank_tiles(frame, rank, world):
@@ -32,7 +48,7 @@ def extract_rank_tiles(frame, rank, world):
         tile = slot * world + rank
         if tile >= tx * ty:
             continue
-        y0, x0 = (tile // tx) * TILE_H, (tile % tx) * TILE_W
+        x0, y0 = tile_origin(tile, tx, world)
         blk = frame[y0:y0 + TILE_H, x0:x0 + TILE_W]
         out[slot, :blk.shape[0], :blk.shape[1]] = blk
     return out
@@ -44,7 +60,7 @@ def assemble_numpy(gathered, width, height, world):
     out = np.zeros((height, width, 3), gathered.dtype)
     for tile in range(tx * ty):
         rank, slot = owner_of_tile(tile, world)
-        y0, x0 = (tile // tx) * TILE_H, (tile % tx) * TILE_W
+        x0, y0 = tile_origin(tile, tx, world)
         hh, ww = min(TILE_H, height - y0), min(TILE_W, width - x0)
         out[y0:y0 + hh, x0:x0 + ww] = gathered[rank, slot, :hh, :ww]
     return out

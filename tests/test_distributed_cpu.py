@@ -79,3 +79,22 @@ def test_tile_ownership_is_a_partition():
         # balanced within one tile
         per = [sum(1 for (r, _) in seen if r == k) for k in range(world)]
         assert max(per) - min(per) <= 1
+        # the tiles' places in the image are a permutation of the grid, and the rotation of the rows makes any
+        # `world` consecutive tiles of a COLUMN belong to `world` different ranks (as those of a row do)
+        skew = tiles.tile_skew(tx, world)
+        place = {}
+        for t in range(tx * ty):
+            x0, y0 = tiles.tile_origin(t, tx, world)
+            place[(x0 // tiles.TILE_W, y0 // tiles.TILE_H)] = t % world
+        assert len(place) == tx * ty
+        if ty >= 2 * world and tx > world:
+            col = [place[(tx // 2, y)] for y in range(world)]
+            assert len(set(col)) == world, (w, h, world, skew, col)
+
+
+def test_tile_skew_matches_the_library(H):
+    from rustraytracer_amd import binding as B, tiles
+    for w in (1920, 3840, 500, 33, 640):
+        for world in (1, 2, 3, 4, 6, 8):
+            assert B.lib.rrt_tile_skew(w, world) == tiles.tile_skew(tiles.tile_grid(w, 8)[0], world), (w, world)
+    assert tiles.tile_skew(60, 8) == 1 and tiles.tile_skew(60, 1) == 0
