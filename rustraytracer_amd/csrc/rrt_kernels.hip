@@ -1175,7 +1175,28 @@ RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y
 }
 
 // One cast() (tracer.rs:177-211) of path `path` at depth `bounce`.
-// What a cast leaves for the next level when the bounce kernel runs in tail mode (the lane carries on itself).
+// Appends the continuation rays of a wave's casts at depth `bounce` to the queue of depth bounce + 1 (all lanes of
+// the wave call this together).  Live rays fill the queue from its front, dead (mix 0.0) rays from its back: a
+// 64-ray unit of the next level is then all live or all dead.  In one mixed queue the units were mixed too (waves of
+// UFO tiles and of sphere tiles append at the same time), and a unit costs what its dearest lane costs: measured
+// 10.7 k cycles for an all-dead unit against 43 k for one with live rays in it.
+RRT_DEV void enqueue_continuation(const DWork& wk, uint32_t bounce, bool cont, bool zero_mix, V3 ro, V3 rd, uint32_t path,
+                                  int32_t medium) {
+    const uint32_t slot_live = queue_slot(&wk.q_count[bounce + 1], cont && !zero_mix);
+    const uint32_t slot_dead = queue_slot(&wk.q_count[kMaxLevels + 1 + bounce + 1], cont && zero_mix);
+    if (cont) {
+        // queue entry {o.xyz, d.xyz, (path, medium)}
+        double* q = wk.q[(bounce + 1) & 1];
+        const uint32_t slot = zero_mix ? (uint32_t)wk.cap - 1u - slot_dead : slot_live;
+        const uint32_t off = slot * (uint32_t)(kRecDoubles * 8);
+        at_off<f64x2>(q, off) = f64x2{ro.x, ro.y};
+        at_off<f64x2>(q, off + 16u) = f64x2{ro.z, rd.x};
+        at_off<f64x2>(q, off + 32u) = f64x2{rd.y, rd.z};
+        at_off<uint2>(q, off + 48u) = make_uint2(path | (zero_mix ? kDeadSky : 0u), (uint32_t)medium);
+    }
+}
+
+// What a cast leaves for the next level when the bounce kernel carries the path on in the same lane.
 struct NextRay {
     V3 o, d;
     int32_t medium;
@@ -1287,26 +1308,11 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
         const unsigned long long zm = __ballot(cont && zero_mix);
         if (zm != 0ull && (int)__lane_id() == __ffsll((long long)zm) - 1) atomicAdd(&wk.stats[3], (unsigned long long)__popcll(zm));
     }
-    // Live rays fill the next queue from its front, dead (mix 0.0) rays from its back: a 64-ray unit of the
-    // next level is then all live or all dead.  In one mixed queue the units were mixed too (waves of UFO
-    // tiles and of sphere tiles append at the same time), and a unit costs what its dearest lane costs:
-    // measured 10.7 k cycles for an all-dead unit against 43 k for one with live rays in it.
     if (!PRIMARY && next) {
         next->o = ro; next->d = rd; next->medium = medium; next->cont = cont; next->zero_mix = zero_mix;
         return;
     }
-    const uint32_t slot_live = queue_slot(&wk.q_count[bounce + 1], cont && !zero_mix);
-    const uint32_t slot_dead = queue_slot(&wk.q_count[kMaxLevels + 1 + bounce + 1], cont && zero_mix);
-    if (cont) {
-        // queue entry {o.xyz, d.xyz, (path, medium)}
-        double* q = wk.q[(bounce + 1) & 1];
-        const uint32_t slot = zero_mix ? (uint32_t)P - 1u - slot_dead : slot_live;
-        const uint32_t off = slot * (uint32_t)(kRecDoubles * 8);
-        at_off<f64x2>(q, off) = f64x2{ro.x, ro.y};
-        at_off<f64x2>(q, off + 16u) = f64x2{ro.z, rd.x};
-        at_off<f64x2>(q, off + 32u) = f64x2{rd.y, rd.z};
-        at_off<uint2>(q, off + 48u) = make_uint2(path | (zero_mix ? kDeadSky : 0u), (uint32_t)medium);
-    }
+    enqueue_continuation(wk, bounce, cont, zero_mix, ro, rd, path, medium);
 }
 
 // Bytes of LDS stage_scene fills (descent array, then entity records); the bounce kernel's unit
@@ -1450,6 +1456,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
 // A bounce level with at most this many rays runs in tail mode (see k_wave_bounce): fewer rays than the chip has
 // wave slots for (256 CUs x 16 waves x 64 lanes = 262 144), so re-queueing them level by level only adds launches.
 constexpr uint32_t kTailRays = 1u << 16;
+constexpr uint32_t kCarryLanes = 0;
 
 // Bounce level `bounce`: the queue is cut into units of 64 rays; block b owns units b, b + grid, ...
 // and its four waves pull them from a counter in LDS.  Rays of a bounce level differ in cost by
@@ -1507,11 +1514,15 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
         }
         const unsigned long long t1 = TSTAMP();
         unsigned long long tch = 0;
-        if (tail) {
-            // Thin level: nothing is gained by queueing its few continuation rays for another launch (a launch whose
-            // rays do not fill the chip lasts as long as its slowest ray: 25-90 us each for the last levels of a
-            // frame).  Each lane carries its own path on to the end; the launches of the deeper levels find their
-            // queues empty.  All lanes of the wave sit at the same depth, so the level stays wave-uniform.
+        // Carry or queue.  A cast's continuation ray normally goes to the queue of the next level, where rays are
+        // compacted into full waves again.  That is worth a launch only for many rays: a thin level (`tail`: fewer
+        // rays than the chip has lanes) carries every path on to its end in its own lane -- a launch whose rays do not
+        // fill the chip lasts as long as its slowest ray, 25-90 us each for the last levels of a frame.  All lanes of a
+        // wave sit at the same depth, so the level stays wave-uniform; the rays of the carried levels are counted
+        // where they are cast.  (kCarryLanes > 0 would also let a wave of a THICK level carry on when only a few of
+        // its rays continue; measured with 16 on cfg2: bounce levels 0.375 -> 0.478 ms -- the nearly empty waves hold
+        // their slots for two more casts and the level's other waves lose their latency hiding.  Left at 0.)
+        {
             bool act = active;
             for (uint32_t b = bounce;;) {
                 NextRay nx;
@@ -1519,16 +1530,19 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
                 act = act && nx.cont;
                 const unsigned long long going = __ballot(act);
                 if (going == 0ull) break;
+                if (!tail && (uint32_t)__popcll(going) > kCarryLanes) {
+                    enqueue_continuation(wk, b, act, nx.zero_mix, nx.o, nx.d, path, nx.medium);
+                    break;
+                }
                 ++b;
-                if (lane == (uint32_t)(__ffsll((long long)going) - 1)) {      // the rays of level b, counted where they are cast
+                if (lane == (uint32_t)(__ffsll((long long)going) - 1)) {
                     const unsigned long long n = (unsigned long long)__popcll(going);
                     atomicAdd(&wk.stats[0], n);
                     if (b < 4u) atomicAdd(&wk.stats[4 + b], n);
                 }
                 o = nx.o; d = nx.d; medium = nx.medium; dead_sky = nx.zero_mix;
             }
-        } else
-        process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, dead_sky, &tch);
+        }
         const unsigned long long t2 = TSTAMP();
         if (__ballot(active && !dead_sky) != 0ull) acc_lc += tch;
         acc_q += t1 - t0; acc_p += t2 - t1; acc_n += 1;

@@ -1,19 +1,19 @@
+#!/bin/bash
+# per-launch start/duration of the last frames of tools/rank_frame.py:  bash tools/ktrace_rank.sh "<rank> <frames> [world]" [ENV=...]
 set -e
+ARGS=${1:-"7 6"}
 cd /tmp && export TMPDIR=/tmp
-for r in 3 7; do
-  timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ktr_$r -- python3 $GRAFT_REPO_ROOT/tools/rank_frame.py $r 6 > $GRAFT_REPO_ROOT/gpurun_out/ktr_$r.log 2>&1
-done
+timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ktr -- python3 $GRAFT_REPO_ROOT/tools/rank_frame.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/ktr.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob
-for r in (3, 7):
-    f = glob.glob("gpurun_out/ktr_%d/**/*kernel_trace.csv" % r, recursive=True)[0]
-    rows = list(csv.DictReader(open(f)))
-    rows = [x for x in rows if "k_wave" in x["Kernel_Name"] or "k_accum" in x["Kernel_Name"]]
-    rows.sort(key=lambda x: int(x["Start_Timestamp"]))
-    last = rows[-10:]
-    t0 = int(last[0]["Start_Timestamp"])
-    print("rank", r)
-    for x in last:
-        print("   %-16s start %8.1f us  dur %7.1f us  grid %s" % (x["Kernel_Name"].split("(")[0].split("::")[-1][:16], (int(x["Start_Timestamp"]) - t0) / 1e3, (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3, x.get("Grid_Size", "")))
+f = sorted(glob.glob("gpurun_out/ktr/**/*kernel_trace.csv", recursive=True))[-1]
+rows = [x for x in csv.DictReader(open(f)) if "k_wave" in x["Kernel_Name"] or "k_accum" in x["Kernel_Name"]]
+rows.sort(key=lambda x: int(x["Start_Timestamp"]))
+last = rows[-14:]
+t0 = int(last[0]["Start_Timestamp"])
+for x in last:
+    name = x["Kernel_Name"]
+    short = "primary" if "primary" in name else "bounce" if "bounce" in name else "accumulate"
+    print("   %-10s queue %-3s start %8.1f us  end %8.1f us  dur %7.1f us" % (short, x.get("Queue_Id", "?"), (int(x["Start_Timestamp"]) - t0) / 1e3, (int(x["End_Timestamp"]) - t0) / 1e3, (int(x["End_Timestamp"]) - int(x["Start_Timestamp"])) / 1e3))
 PY
