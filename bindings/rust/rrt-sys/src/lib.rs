@@ -116,6 +116,10 @@ extern "C" {
                                verts: *mut *mut f64, normals: *mut *mut f64, n_triangles: *mut i64) -> c_int;
     pub fn rrt_host_add_model(s: *mut rrt_scene, obj_path: *const c_char, material: c_int,
                               position: *const f64, scale: *const f64) -> c_int;
+    pub fn rrt_host_load_model_ex(obj_path: *const c_char, position: *const f64, scale: *const f64, flags: u32,
+                                  verts: *mut *mut f64, normals: *mut *mut f64, n_triangles: *mut i64) -> c_int;
+    pub fn rrt_host_add_model_ex(s: *mut rrt_scene, obj_path: *const c_char, material: c_int,
+                                 position: *const f64, scale: *const f64, flags: u32) -> c_int;
     pub fn rrt_host_load_png_rgb8(path: *const c_char, rgb8: *mut *mut u8, w: *mut u32, h: *mut u32) -> c_int;
     pub fn rrt_host_save_png_rgb8(path: *const c_char, rgb8: *const u8, w: u32, h: u32) -> c_int;
     pub fn rrt_host_load_cubemap(s: *mut rrt_scene, folder: *const c_char) -> c_int;

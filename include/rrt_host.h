@@ -31,13 +31,27 @@ extern "C" {
 int rrt_host_load_model(const char* obj_path, const double position[3], const double scale[3], double** verts,
                         double** normals, int64_t* n_triangles);
 
+/* The same with options.  RRT_OBJ_TRIANGULATE (EXTENSION; obj-rs 0.6.2 has no such mode and the reference
+ * would panic at model.rs:27): a face with more than three corners is taken as the triangle fan
+ * (c0, ci, ci+1), so that the reference's own obj/ufo.obj (789 quads, 38 triangles, 12 n-gons, "v/vt/vn"
+ * corners) loads; everything else -- f32 parse, transform, averaged normals, the dropped last triangle --
+ * is as rrt_host_load_model.  flags = 0 is rrt_host_load_model. */
+#define RRT_OBJ_TRIANGULATE 1u
+int rrt_host_load_model_ex(const char* obj_path, const double position[3], const double scale[3], uint32_t flags,
+                           double** verts, double** normals, int64_t* n_triangles);
+int rrt_host_add_model_ex(rrt_scene* s, const char* obj_path, int material, const double position[3],
+                          const double scale[3], uint32_t flags);
+
 /* Model::new(path, material, position, scale) + world.entities.push
  * (src/geometry/model.rs:24-56, src/main.rs:61).  Returns the entity id. */
 int rrt_host_add_model(rrt_scene* s, const char* obj_path, int material, const double position[3],
                        const double scale[3]);
 
-/* image::open(path).to_rgb8(): 8-bit PNG of colour type grey / RGB / palette /
- * grey+alpha / RGBA, non-interlaced; alpha is dropped, palettes expanded.
+/* image::open(path).to_rgb8() for PNG: every colour type (grey, RGB, palette, grey+alpha, RGBA) at every
+ * bit depth the format allows (1/2/4/8/16), plain or Adam7-interlaced; alpha is dropped, palettes are
+ * expanded, grey is replicated (packed grey scaled to 0..255), 16-bit samples keep their high byte
+ * (image 0.23.14 downcast_channel).  The reference's own cubemaps are 8-bit RGB / RGBA / palette,
+ * non-interlaced; the rest is covered by generated fixtures (tests/golden/png/).
  * *rgb8 is malloc'ed (h rows of w texels). */
 int rrt_host_load_png_rgb8(const char* path, uint8_t** rgb8, uint32_t* w, uint32_t* h);
 

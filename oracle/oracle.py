@@ -106,7 +106,8 @@ def color_vec(r, g, b):
 # Model::new restated (model.rs:24-56).  obj-rs 0.6.2 semantics: numbers parsed
 # as f32; faces must be triangles with position+normal ("v//vn" or "v/vt/vn").
 # ---------------------------------------------------------------------------
-def parse_obj(path):
+def parse_obj(path, triangulate=False):
+    """triangulate: EXTENSION (obj-rs has no such mode) -- a polygon becomes the fan (c0, ci, ci+1)."""
     pos, nrm, faces = [], [], []
     with open(path, "r") as f:
         for line in f:
@@ -118,7 +119,7 @@ def parse_obj(path):
             elif tok[0] == "vn":
                 nrm.append([np.float32(t) for t in tok[1:4]])
             elif tok[0] == "f":
-                if len(tok) != 4:
+                if len(tok) < 4 or (len(tok) != 4 and not triangulate):
                     raise ValueError("obj-rs refuses untriangulated faces: " + line.strip())
                 corner = []
                 for t in tok[1:]:
@@ -129,7 +130,8 @@ def parse_obj(path):
                     pi = pi - 1 if pi > 0 else len(pos) + pi
                     ni = ni - 1 if ni > 0 else len(nrm) + ni
                     corner.append((pi, ni))
-                faces.append(corner)
+                for i in range(1, len(corner) - 1):
+                    faces.append([corner[0], corner[i], corner[i + 1]])
     P = np.asarray(pos, dtype=np.float32).reshape(-1, 3)
     N = np.asarray(nrm, dtype=np.float32).reshape(-1, 3)
     F = np.asarray(faces, dtype=np.int64).reshape(-1, 3, 2)
@@ -142,11 +144,11 @@ def _normalize_rows(v):
     return v * (1.0 / np.sqrt(m2))[..., None]
 
 
-def load_model(path, position, scale):
+def load_model(path, position, scale, triangulate=False):
     """Returns (verts[N,3,3] f64, normals[N,3] f64) with the last face dropped
     (model.rs:31), T*S transform on positions (model.rs:29-41) and averaged,
     untransformed flat normals (model.rs:35-42)."""
-    P, Nn, F = parse_obj(path)
+    P, Nn, F = parse_obj(path, triangulate)
     nfaces = F.shape[0]
     n_idx = 3 * nfaces
     # for i in (0..indices.len()-4).step_by(3)

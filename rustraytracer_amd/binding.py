@@ -47,7 +47,7 @@ EXPORTS = [
     "rrt_render", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_tile_skew", "rrt_assemble_tiles",
     "rrt_trace_rays", "rrt_cast_rays", "rrt_get_stats", "rrt_mesh_tree_sizes",
     "rrt_mesh_tree_export", "rrt_selftest_math", "rrt_philox4x32_10",
-    "rrt_host_load_model", "rrt_host_add_model", "rrt_host_load_png_rgb8",
+    "rrt_host_load_model", "rrt_host_add_model", "rrt_host_load_model_ex", "rrt_host_add_model_ex", "rrt_host_load_png_rgb8",
     "rrt_host_save_png_rgb8", "rrt_host_load_cubemap", "rrt_host_free",
 ]
 
@@ -114,6 +114,8 @@ def _load():
     L.rrt_philox4x32_10.restype = None
     L.rrt_host_load_model.argtypes = [C.c_char_p, dp, dp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
     L.rrt_host_add_model.argtypes = [vp, C.c_char_p, i32, dp, dp]
+    L.rrt_host_load_model_ex.argtypes = [C.c_char_p, dp, dp, u32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]
+    L.rrt_host_add_model_ex.argtypes = [vp, C.c_char_p, i32, dp, dp, u32]
     L.rrt_host_load_png_rgb8.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]
     L.rrt_host_save_png_rgb8.argtypes = [C.c_char_p, vp, u32, u32]
     L.rrt_host_load_cubemap.argtypes = [vp, C.c_char_p]

@@ -70,7 +70,7 @@ static bool parse_index_triplet(const char* tok, long* p, long* t, long* n, bool
     return *e3 == '\0';
 }
 
-static int read_obj(const char* path, ObjData* out) {
+static int read_obj(const char* path, ObjData* out, bool triangulate) {
     FILE* f = std::fopen(path, "rb");
     if (!f) return hfail(RRT_E_IO, std::string("cannot open ") + path);
     std::string line;
@@ -101,12 +101,14 @@ static int read_obj(const char* path, ObjData* out) {
             std::vector<float>& dst = tok[0] == "v" ? out->pos : out->nrm;
             for (int k = 1; k <= 3; ++k) dst.push_back(std::strtof(tok[k].c_str(), nullptr));  // f32, as obj-rs
         } else if (tok[0] == "f") {
-            if (tok.size() != 4) {
+            if (tok.size() < 4 || (tok.size() != 4 && !triangulate)) {
                 rc = hfail(RRT_E_FORMAT, std::string(path) + ":" + std::to_string(lineno) +
-                                             ": face is not a triangle (obj-rs load_obj refuses untriangulated models)");
+                                             ": face is not a triangle (obj-rs load_obj refuses untriangulated models; "
+                                             "RRT_OBJ_TRIANGULATE fans them)");
                 break;
             }
-            for (int k = 1; k <= 3; ++k) {
+            std::vector<int32_t> cp, cn;      // the face's corners
+            for (size_t k = 1; k < tok.size(); ++k) {
                 long p, t, n;
                 bool has_n;
                 if (!parse_index_triplet(tok[k].c_str(), &p, &t, &n, &has_n) || !has_n) {
@@ -121,8 +123,17 @@ static int read_obj(const char* path, ObjData* out) {
                     rc = hfail(RRT_E_FORMAT, std::string(path) + ":" + std::to_string(lineno) + ": index out of range");
                     break;
                 }
-                out->face_p.push_back((int32_t)p);
-                out->face_n.push_back((int32_t)n);
+                cp.push_back((int32_t)p);
+                cn.push_back((int32_t)n);
+            }
+            if (rc != RRT_OK) break;
+            // a triangle as it stands; a polygon (EXTENSION, RRT_OBJ_TRIANGULATE) as the fan (c0, ci, ci+1)
+            for (size_t i = 1; i + 1 < cp.size(); ++i) {
+                const size_t tri[3] = {0, i, i + 1};
+                for (size_t c : tri) {
+                    out->face_p.push_back(cp[c]);
+                    out->face_n.push_back(cn[c]);
+                }
             }
         }
         // o, g, s, vt, usemtl, mtllib: irrelevant to Vertex{position, normal}
@@ -138,9 +149,9 @@ static void norm3(const double in[3], double out[3]) {   // cgmath normalize
 }
 
 int load_model(const char* path, const double position[3], const double scale[3], std::vector<double>* verts,
-               std::vector<double>* normals) {
+               std::vector<double>* normals, uint32_t flags) {
     ObjData o;
-    int rc = read_obj(path, &o);
+    int rc = read_obj(path, &o, (flags & RRT_OBJ_TRIANGULATE) != 0);
     if (rc) return rc;
     const long n_idx = (long)o.face_p.size();
     if (n_idx < 5) return hfail(RRT_E_FORMAT, std::string(path) + ": fewer than two faces (model.rs:31 would underflow)");
@@ -220,7 +231,7 @@ int load_png_rgb8(const char* path, std::vector<uint8_t>* rgb, uint32_t* w_out, 
         at += 12 + (size_t)len;
     }
     if (w == 0 || h == 0 || ctype < 0) return hfail(RRT_E_FORMAT, std::string(path) + ": missing IHDR");
-    if (interlace) return hfail(RRT_E_FORMAT, std::string(path) + ": interlaced PNG not supported");
+    if (interlace > 1) return hfail(RRT_E_FORMAT, std::string(path) + ": unknown interlace method");
     int channels;
     switch (ctype) {
         case 0: channels = 1; break;
@@ -230,58 +241,84 @@ int load_png_rgb8(const char* path, std::vector<uint8_t>* rgb, uint32_t* w_out, 
         case 6: channels = 4; break;
         default: return hfail(RRT_E_FORMAT, std::string(path) + ": bad colour type");
     }
-    if (!(depth == 8 || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4))))
-        return hfail(RRT_E_FORMAT, std::string(path) + ": only 8-bit samples (or packed palettes) are supported");
+    const bool low = depth == 1 || depth == 2 || depth == 4;
+    if (!(depth == 8 || depth == 16 || (low && (ctype == 0 || ctype == 3))) || (ctype == 3 && depth == 16))
+        return hfail(RRT_E_FORMAT, std::string(path) + ": bit depth " + std::to_string(depth) + " is not valid for colour type " + std::to_string(ctype));
     const size_t bits_pp = (size_t)channels * depth;
-    const size_t stride = ((size_t)w * bits_pp + 7) / 8;
-    const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
-    std::vector<uint8_t> raw((stride + 1) * (size_t)h);
+    const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;      // filter distance in bytes
+    // the image, or its seven Adam7 sub-images (x0, y0, dx, dy), each a run of filtered scanlines of its own
+    static const uint32_t kPass[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    struct Pass { uint32_t x0, y0, dx, dy, pw, ph; size_t stride; };
+    std::vector<Pass> passes;
+    size_t raw_size = 0;
+    for (int k = 0; k < (interlace ? 7 : 1); ++k) {
+        Pass ps;
+        if (interlace) { ps.x0 = kPass[k][0]; ps.y0 = kPass[k][1]; ps.dx = kPass[k][2]; ps.dy = kPass[k][3]; }
+        else { ps.x0 = ps.y0 = 0; ps.dx = ps.dy = 1; }
+        ps.pw = w > ps.x0 ? (w - ps.x0 + ps.dx - 1) / ps.dx : 0;
+        ps.ph = h > ps.y0 ? (h - ps.y0 + ps.dy - 1) / ps.dy : 0;
+        if (ps.pw == 0 || ps.ph == 0) continue;            // an empty pass has no scanlines at all
+        ps.stride = ((size_t)ps.pw * bits_pp + 7) / 8;
+        raw_size += (ps.stride + 1) * (size_t)ps.ph;
+        passes.push_back(ps);
+    }
+    std::vector<uint8_t> raw(raw_size);
     uLongf raw_len = (uLongf)raw.size();
     const int zr = uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size());
     if (zr != Z_OK || raw_len != raw.size()) return hfail(RRT_E_FORMAT, std::string(path) + ": zlib inflate failed");
-    std::vector<uint8_t> img(stride * (size_t)h);
-    for (uint32_t y = 0; y < h; ++y) {
-        const uint8_t ft = raw[(stride + 1) * y];
-        const uint8_t* in = &raw[(stride + 1) * y + 1];
-        uint8_t* cur = &img[stride * y];
-        const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= bpp ? cur[i - bpp] : 0;
-            const int b = up ? up[i] : 0;
-            const int c = (up && i >= bpp) ? up[i - bpp] : 0;
-            int v = in[i];
-            switch (ft) {
-                case 0: break;
-                case 1: v += a; break;
-                case 2: v += b; break;
-                case 3: v += (a + b) / 2; break;
-                case 4: v += paeth(a, b, c); break;
-                default: return hfail(RRT_E_FORMAT, std::string(path) + ": bad filter type");
-            }
-            cur[i] = (uint8_t)v;
-        }
-    }
     rgb->assign((size_t)w * h * 3, 0);
-    for (uint32_t y = 0; y < h; ++y) {
-        const uint8_t* row = &img[stride * y];
-        uint8_t* dst = &(*rgb)[(size_t)y * w * 3];
-        for (uint32_t x = 0; x < w; ++x) {
-            uint8_t r, g, b;
-            if (ctype == 2) { r = row[3 * x]; g = row[3 * x + 1]; b = row[3 * x + 2]; }
-            else if (ctype == 6) { r = row[4 * x]; g = row[4 * x + 1]; b = row[4 * x + 2]; }
-            else if (ctype == 0) { r = g = b = row[x]; }
-            else if (ctype == 4) { r = g = b = row[2 * x]; }
-            else {
-                uint32_t idx;
-                if (depth == 8) idx = row[x];
-                else {
-                    const uint32_t per = 8 / depth, sh = (per - 1 - x % per) * depth;
-                    idx = (row[x / per] >> sh) & ((1u << depth) - 1);
+    // image 0.23.14 `to_rgb8`: alpha dropped, palettes expanded, grey replicated, packed grey scaled to 0..255, and a
+    // 16-bit sample reduced to its HIGH byte (color.rs downcast_channel: c16 >> 8) -- no 16-bit asset exists in the
+    // reference, so that last rule is restated from the crate's source as remembered: parity unpinned.
+    const auto sample8 = [&](const uint8_t* row, size_t idx) -> uint32_t {      // idx-th sample of a scanline
+        if (depth == 8) return row[idx];
+        if (depth == 16) return row[2 * idx];
+        const uint32_t per = 8u / (uint32_t)depth, sh = (per - 1 - (uint32_t)(idx % per)) * (uint32_t)depth;
+        return (row[idx / per] >> sh) & ((1u << depth) - 1u);
+    };
+    size_t at_raw = 0;
+    std::vector<uint8_t> prev, cur;
+    for (const Pass& ps : passes) {
+        prev.assign(ps.stride, 0);
+        cur.assign(ps.stride, 0);
+        for (uint32_t py = 0; py < ps.ph; ++py) {
+            const uint8_t ft = raw[at_raw];
+            const uint8_t* in = &raw[at_raw + 1];
+            at_raw += ps.stride + 1;
+            for (size_t i = 0; i < ps.stride; ++i) {
+                const int a = i >= bpp ? cur[i - bpp] : 0;
+                const int b = prev[i];
+                const int c = i >= bpp ? prev[i - bpp] : 0;
+                int v = in[i];
+                switch (ft) {
+                    case 0: break;
+                    case 1: v += a; break;
+                    case 2: v += b; break;
+                    case 3: v += (a + b) / 2; break;
+                    case 4: v += paeth(a, b, c); break;
+                    default: return hfail(RRT_E_FORMAT, std::string(path) + ": bad filter type");
                 }
-                if (3 * (size_t)idx + 2 >= plte.size()) return hfail(RRT_E_FORMAT, std::string(path) + ": palette index out of range");
-                r = plte[3 * idx]; g = plte[3 * idx + 1]; b = plte[3 * idx + 2];
+                cur[i] = (uint8_t)v;
             }
-            dst[3 * x] = r; dst[3 * x + 1] = g; dst[3 * x + 2] = b;
+            const uint32_t y = ps.y0 + py * ps.dy;
+            for (uint32_t px = 0; px < ps.pw; ++px) {
+                const uint32_t x = ps.x0 + px * ps.dx;
+                uint32_t r, g, b;
+                if (ctype == 2 || ctype == 6) {
+                    r = sample8(cur.data(), (size_t)channels * px); g = sample8(cur.data(), (size_t)channels * px + 1); b = sample8(cur.data(), (size_t)channels * px + 2);
+                } else if (ctype == 0 || ctype == 4) {
+                    r = sample8(cur.data(), (size_t)channels * px);
+                    if (low) r = r * 255u / ((1u << depth) - 1u);
+                    g = b = r;
+                } else {
+                    const uint32_t idx = sample8(cur.data(), px);
+                    if (3 * (size_t)idx + 2 >= plte.size()) return hfail(RRT_E_FORMAT, std::string(path) + ": palette index out of range");
+                    r = plte[3 * idx]; g = plte[3 * idx + 1]; b = plte[3 * idx + 2];
+                }
+                uint8_t* dst = &(*rgb)[((size_t)y * w + x) * 3];
+                dst[0] = (uint8_t)r; dst[1] = (uint8_t)g; dst[2] = (uint8_t)b;
+            }
+            prev.swap(cur);
         }
     }
     *w_out = w;
@@ -329,10 +366,15 @@ int save_png_rgb8(const char* path, const uint8_t* rgb, uint32_t w, uint32_t h) 
 extern "C" {
 
 int rrt_host_load_model(const char* obj_path, const double position[3], const double scale[3], double** verts,
-                        double** normals, int64_t* n_triangles) try {
+                        double** normals, int64_t* n_triangles) {
+    return rrt_host_load_model_ex(obj_path, position, scale, 0u, verts, normals, n_triangles);
+}
+
+int rrt_host_load_model_ex(const char* obj_path, const double position[3], const double scale[3], uint32_t flags,
+                           double** verts, double** normals, int64_t* n_triangles) try {
     if (!obj_path || !position || !scale || !verts || !normals || !n_triangles) return rrt::hfail(RRT_E_INVALID, "null argument");
     std::vector<double> v, n;
-    const int rc = rrt::load_model(obj_path, position, scale, &v, &n);
+    const int rc = rrt::load_model(obj_path, position, scale, &v, &n, flags);
     if (rc) return rc;
     *n_triangles = (int64_t)(n.size() / 3);
     *verts = (double*)std::malloc(v.size() * sizeof(double) + 8);
@@ -345,10 +387,15 @@ int rrt_host_load_model(const char* obj_path, const double position[3], const do
     return rrt::host_on_exception();
 }
 
-int rrt_host_add_model(rrt_scene* s, const char* obj_path, int material, const double position[3], const double scale[3]) try {
+int rrt_host_add_model(rrt_scene* s, const char* obj_path, int material, const double position[3], const double scale[3]) {
+    return rrt_host_add_model_ex(s, obj_path, material, position, scale, 0u);
+}
+
+int rrt_host_add_model_ex(rrt_scene* s, const char* obj_path, int material, const double position[3], const double scale[3],
+                          uint32_t flags) try {
     if (!s || !obj_path || !position || !scale) return rrt::hfail(RRT_E_INVALID, "null argument");
     std::vector<double> v, n;
-    const int rc = rrt::load_model(obj_path, position, scale, &v, &n);
+    const int rc = rrt::load_model(obj_path, position, scale, &v, &n, flags);
     if (rc) return rc;
     return rrt_add_mesh(s, v.data(), n.data(), (int64_t)(n.size() / 3), material);
 } catch (...) {

@@ -39,9 +39,10 @@ class loaders:
     """Asset loaders implemented in the product's C++ host layer (host_io.cpp)."""
 
     @staticmethod
-    def load_model(path, position, scale):
+    def load_model(path, position, scale, triangulate=False):
         v, n, cnt = C.c_void_p(), C.c_void_p(), C.c_int64()
-        B.check(B.lib.rrt_host_load_model(path.encode(), _d3(position), _d3(scale), C.byref(v), C.byref(n), C.byref(cnt)))
+        B.check(B.lib.rrt_host_load_model_ex(path.encode(), _d3(position), _d3(scale), 1 if triangulate else 0,
+                                             C.byref(v), C.byref(n), C.byref(cnt)))
         try:
             nt = cnt.value
             verts = np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_double)), shape=(nt, 3, 3)).copy()

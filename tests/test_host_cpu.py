@@ -256,3 +256,53 @@ def test_translate_host_side_matches_oracle_and_rebuild(H, O, scenes):
         w.add_point_light((0, 0, 0), (1, 1, 1), 1.0, 1.0)
     with pytest.raises(B.RrtError, match="shadow mode"):
         w.set_shadow_mode(2)
+
+
+def test_png_decoder_fixtures(H, golden_dir):
+    """to_rgb8 over the whole PNG format: Adam7, 16-bit, packed grey and palettes, grey+alpha,
+    all five filters, two IDAT chunks, sizes with empty Adam7 passes.  Files and expected images come from
+    tests/golden/make_png_fixtures.py; PIL decodes them too, as an independent reader (where its own to-RGB
+    conversion means the same thing: 8-bit and palette files)."""
+    from PIL import Image
+    d = os.path.join(golden_dir, "png")
+    exp = np.load(os.path.join(d, "expected.npz"))
+    assert len(exp.files) == 17
+    for name in exp.files:
+        got = H.loaders.load_png(os.path.join(d, name + ".png"))
+        assert got.shape == exp[name].shape and np.array_equal(got, exp[name]), name
+        if "16" not in name and not name.startswith("grey1") and not name.startswith("grey2") and not name.startswith("grey4"):
+            pil = np.asarray(Image.open(os.path.join(d, name + ".png")).convert("RGB"))
+            assert np.array_equal(pil, exp[name]), name
+    from rustraytracer_amd import binding as B
+    bad = os.path.join(d, "expected.npz")
+    with pytest.raises(B.RrtError, match="not a PNG"):
+        H.loaders.load_png(bad)
+
+
+def test_obj_triangulation_loads_the_reference_ufo(H, O, scenes, tmp_path):
+    """RRT_OBJ_TRIANGULATE (extension): quads and n-gons become fans, so the file BASELINE.json names, obj/ufo.obj
+    (789 quads, 38 triangles, 12 n-gons with v/vt/vn corners), loads -- same triangles as the oracle-side numpy
+    loader produces, and its kd-tree equals the oracle's.  Without the flag it is refused, as obj-rs refuses it."""
+    from rustraytracer_amd import binding as B
+    p = os.path.join(scenes.ASSETS, "obj", "ufo.obj")
+    with pytest.raises(B.RrtError, match="not a triangle"):
+        H.loaders.load_model(p, (0, 30, 70), (1, -1, 1))
+    v, n = H.loaders.load_model(p, (0, 30, 70), (1, -1, 1), triangulate=True)
+    vo, no = O.load_model(p, (0, 30, 70), (1, -1, 1), triangulate=True)
+    assert np.array_equal(v, vo) and np.array_equal(n, no)
+    assert len(v) == 38 + 789 * 2 + 8 * 3 + 2 * 15 + 2 * 18 - 1          # fans, minus the face model.rs:31 drops
+    g, c = H.World(), O.OracleScene()
+    for s in (g, c):
+        s.add_mesh(v, n, s.add_material((0.4, 0.4, 0.2), 1.0, 1.0, 0.0, 0.3, 20))
+    tg, tc = g.tree(0), c.tree(0)
+    assert all(np.array_equal(tg[k], tc[k]) for k in tg)
+    # a triangulated file is unchanged by the flag; a pentagon fans in corner order
+    a = H.loaders.load_model(os.path.join(scenes.ASSETS, "obj", "ufo_fix.obj"), (0, 30, 70), (1, -1, 1), triangulate=True)
+    b = H.loaders.load_model(os.path.join(scenes.ASSETS, "obj", "ufo_fix.obj"), (0, 30, 70), (1, -1, 1))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    pent = tmp_path / "pent.obj"
+    pent.write_text("v 0 0 0\nv 2 0 0\nv 3 1 0\nv 1 3 0\nv -1 1 0\nvn 0 0 1\nf 1//1 2//1 3//1 4//1 5//1\nf 1//1 2//1 3//1\n")
+    pv, _ = H.loaders.load_model(str(pent), (0, 0, 0), (1, 1, 1), triangulate=True)
+    assert pv.shape == (3, 3, 3)
+    assert np.array_equal(pv[:, 0, :2], [[0, 0]] * 3) and np.array_equal(pv[:, 1, :2], [[2, 0], [3, 1], [1, 3]]) \
+        and np.array_equal(pv[:, 2, :2], [[3, 1], [1, 3], [-1, 1]])

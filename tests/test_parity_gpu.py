@@ -518,6 +518,25 @@ def test_dead_reflection_rays_are_value_identical(H, O, scenes):
         assert go["stats"]["zero_mix_paths"] > 10000
 
 
+def test_reference_ufo_obj_quads_and_ngons(H, O, scenes):
+    """The file BASELINE.json names, obj/ufo.obj (quads and n-gons; obj-rs would refuse it, so main.rs loads
+    ufo_fix.obj): loaded with the fan-triangulation extension by the product's C++ loader on one side and the
+    oracle-side numpy loader on the other, rendered in the main.rs world -- bit-exact, parity unpinned against the
+    reference (it cannot load this file at all)."""
+    def build(b, L):
+        scenes.empty_world(b, L, "hd_blue_sunset")
+        mat = b.add_material(scenes.color_vec(100, 100, 50), 1.0, 1.0, 0.0, 0.3, 20)
+        mir = b.add_material(scenes.color_vec(0, 0, 0), 0.8, 0.0, 1.0, 0.1, 20)
+        v, n = L.load_model(os.path.join(scenes.ASSETS, "obj", "ufo.obj"), (0.0, 30.0, 70.0), (1.0, -1.0, 1.0), triangulate=True)
+        b.add_mesh(v, n, mat)
+        b.add_sphere((2.0, 0.0, 8.0), 1.0, mir)
+        return b
+    g, c = build(H.World(device=0), H.loaders), build(O.OracleScene(), O)
+    go, co = g.render(640, 360, spp=2, seed=1), c.render(640, 360, spp=2, seed=1)
+    _same(go, co)
+    assert (go["ids"][..., 0] == 0).sum() > 5000 and go["stats"]["traversal_overflow"] == 0
+
+
 def test_cpp_host_main_rs_writes_bruh_png(golden_dir, tmp_path):
     """examples/main.cpp = src/main.rs restated on the C++ host mirror (include/rrt_host.hpp);
     the PNG it writes through the C ABI must decode to the reference's bruh.png."""
