@@ -121,7 +121,7 @@ struct rrt_scene {
     bool has_light = false;
     double light_dir[3] = {0, 0, 0}, light_color[3] = {0, 0, 0}, light_intensity = 0.0;
     double ambient = 0.15;  // tracer.rs:73
-    uint64_t work_budget = 16ull << 30;
+    uint64_t work_budget = 32ull << 30;   // of 288 GB; a batch is also capped by 32-bit record offsets (76.7 M paths = 27.9 GB)
     int cull_mode = 1;
     int timing = 2;        // rrt_set_timing: 0 no events, 1 frame begin/end, 2 + per-kernel pairs
 
