@@ -263,7 +263,10 @@ def main():
     scene.commit()                                   # scene resident in HBM before timing
 
     frame = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
-    pipe = D.TilePipeline(scene, w, h, world, dev, frame) if world > 1 else None
+    # RRT_BENCH_GATHER=native: the gather goes through librrt.so's own RCCL communicator (rrt_comm_*, the path of
+    # a host without Python) instead of torch.distributed's; torch's group still carries the id and the barriers
+    native = D.NativeComm(rank, world, dev) if world > 1 and os.environ.get("RRT_BENCH_GATHER", "torch") == "native" else None
+    pipe = D.TilePipeline(scene, w, h, world, dev, frame, native=native) if world > 1 else None
     if world > 1:
         scene.set_timing(0)      # no hipEvents between the launches of a rank's sub-millisecond frames (N = 1 keeps them:
                                  # the roofline needs the primary kernel's live duration)

@@ -11,6 +11,12 @@ pub struct rrt_scene {
     _private: [u8; 0],
 }
 
+/// Opaque communicator of the tile gather (`typedef struct rrt_comm rrt_comm`).
+#[repr(C)]
+pub struct rrt_comm {
+    _private: [u8; 0],
+}
+
 /// `rrt_camera`: `RayTracer::new_default_renderer` + the lens set-up of `render`
 /// (src/tracer.rs:38-51, 84-110).
 #[repr(C)]
@@ -102,6 +108,11 @@ extern "C" {
                                      stream: *mut c_void) -> c_int;
     pub fn rrt_noalloc_scratch_bytes() -> u64;
     pub fn rrt_tile_skew(width: u32, tile_world: u32) -> u32;
+    pub fn rrt_comm_unique_id(id128: *mut c_void) -> c_int;
+    pub fn rrt_comm_init(rank: c_int, world: c_int, id128: *const c_void, out: *mut *mut rrt_comm) -> c_int;
+    pub fn rrt_comm_destroy(c: *mut rrt_comm);
+    pub fn rrt_gather_tiles(c: *mut rrt_comm, d_local: *const c_void, d_gathered: *mut c_void, width: u32, height: u32,
+                            root: c_int, stream: *mut c_void) -> c_int;
     pub fn rrt_tile_slots(width: u32, height: u32, tile_world: u32) -> i64;
     pub fn rrt_assemble_tiles(d_gathered: *const c_void, width: u32, height: u32, tile_world: u32,
                               d_rgb8: *mut c_void, stream: *mut c_void) -> c_int;

@@ -278,6 +278,25 @@ int64_t rrt_tile_slots(uint32_t width, uint32_t height, uint32_t tile_world);
 int rrt_assemble_tiles(const void* d_gathered, uint32_t width, uint32_t height, uint32_t tile_world, void* d_rgb8,
                        void* stream);
 
+/* The frame's one exchange step for hosts that are not Python (no reference counterpart: the reference
+ * is one process, src/tracer.rs:117-158).  One process per GPU; RCCL over xGMI inside the library,
+ * resolved at run time (a process that already holds an RCCL shares it; a single-GPU host never loads it).
+ *   rrt_comm_unique_id   one rank creates the 128-byte id and hands it to the others by whatever means
+ *                        the host has (a file, an environment variable, MPI, a socket);
+ *   rrt_comm_init        every rank, after rrt_set_device(LOCAL_RANK): ncclCommInitRank;
+ *   rrt_gather_tiles     d_local = this rank's compact tile buffer (rrt_render_device with tile_world > 1),
+ *                        d_gathered = [tile_world][rrt_tile_slots()][8][32][3] on the receiving rank(s);
+ *                        root >= 0: every peer sends straight to that rank (xGMI is point to point: the
+ *                        messages arrive side by side), root = -1: all-gather.  Asynchronous on `stream`;
+ *                        follow it with rrt_assemble_tiles on the same stream. */
+#define RRT_COMM_ID_BYTES 128
+typedef struct rrt_comm rrt_comm;
+int rrt_comm_unique_id(void* id128);
+int rrt_comm_init(int rank, int world, const void* id128, rrt_comm** out);
+void rrt_comm_destroy(rrt_comm* c);
+int rrt_gather_tiles(rrt_comm* c, const void* d_local, void* d_gathered, uint32_t width, uint32_t height, int root,
+                     void* stream);
+
 /* The closest-hit loop of RayTracer::cast over world.entities
  * (src/tracer.rs:178-190 calling Entity::collide, common.rs:42) for caller
  * supplied rays (6 doubles each: origin, direction).  Host pointers; outputs

@@ -44,7 +44,7 @@ EXPORTS = [
     "rrt_set_directional_light", "rrt_set_ambient", "rrt_add_point_light", "rrt_set_shadow_mode", "rrt_translate_entity",
     "rrt_occluded_rays", "rrt_set_work_budget", "rrt_set_cull_mode", "rrt_set_timing",
     "rrt_scene_commit",
-    "rrt_render", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_tile_skew", "rrt_assemble_tiles",
+    "rrt_render", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_tile_skew", "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_gather_tiles", "rrt_assemble_tiles",
     "rrt_trace_rays", "rrt_cast_rays", "rrt_get_stats", "rrt_mesh_tree_sizes",
     "rrt_mesh_tree_export", "rrt_selftest_math", "rrt_philox4x32_10",
     "rrt_host_load_model", "rrt_host_add_model", "rrt_host_load_model_ex", "rrt_host_add_model_ex", "rrt_host_load_png_rgb8",
@@ -99,6 +99,11 @@ def _load():
     L.rrt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp, vp]
     L.rrt_render_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp, vp]
     L.rrt_noalloc_scratch_bytes.restype = u64
+    L.rrt_comm_unique_id.argtypes = [vp]
+    L.rrt_comm_init.argtypes = [i32, i32, vp, C.POINTER(vp)]
+    L.rrt_comm_destroy.argtypes = [vp]
+    L.rrt_comm_destroy.restype = None
+    L.rrt_gather_tiles.argtypes = [vp, vp, vp, u32, u32, i32, vp]
     L.rrt_tile_skew.argtypes = [u32, u32]
     L.rrt_tile_skew.restype = u32
     L.rrt_tile_slots.argtypes = [u32, u32, u32]

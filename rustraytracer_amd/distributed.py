@@ -27,6 +27,38 @@ def _host_staged():
     return dist.get_backend() == "gloo"
 
 
+class NativeComm:
+    """The library's own RCCL communicator (include/rrt.h: rrt_comm_*), the path a host without Python uses.
+    The 128-byte id travels over the already initialised torch.distributed group here; a C++ / Rust host would
+    hand it over by file, environment or MPI."""
+
+    def __init__(self, rank, world, device):
+        import ctypes as C
+        from . import binding as B
+        self._B, self._C = B, C
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            B.check(B.lib.rrt_comm_unique_id(buf))
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        if world > 1:
+            staged = ident if _host_staged() else ident.to(device)
+            dist.broadcast(staged, src=0)
+            ident = staged.cpu()
+        raw = (C.c_uint8 * 128)(*ident.tolist())
+        self.h = C.c_void_p()
+        B.check(B.lib.rrt_set_device(device.index if device.index is not None else 0))
+        B.check(B.lib.rrt_comm_init(rank, world, raw, C.byref(self.h)))
+
+    def gather(self, local, gathered, width, height, root=-1, stream=None):
+        self._B.check(self._B.lib.rrt_gather_tiles(self.h, local.data_ptr(), gathered.data_ptr(), width, height, root, stream))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._B.lib.rrt_comm_destroy(self.h)
+            self.h = None
+
+
 def gather_tiles(local, gathered):
     """The frame's only collective.  Every rank ends with every rank's tiles."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
@@ -50,8 +82,9 @@ class TilePipeline:
     and the de-interleave of a frame run on a second stream behind an event; the tile buffers are
     double-buffered so that render i+1 never writes what gather i still reads."""
 
-    def __init__(self, scene, width, height, world, device, frame):
+    def __init__(self, scene, width, height, world, device, frame, native=None):
         from . import host as H
+        self.native = native          # a NativeComm: gather to rank 0 through librrt.so's own RCCL calls
         self._H = H
         self.scene, self.w, self.h, self.world, self.frame = scene, width, height, world, frame
         self.local, self.gathered = [], []
@@ -73,7 +106,10 @@ class TilePipeline:
         self.ev_render[k].record(self.s_render)
         with torch.cuda.stream(self.s_comm):
             self.s_comm.wait_event(self.ev_render[k])
-            gather_tiles(self.local[k], self.gathered[k])
+            if self.native is not None:
+                self.native.gather(self.local[k], self.gathered[k], self.w, self.h, root=-1, stream=self.s_comm.cuda_stream)
+            else:
+                gather_tiles(self.local[k], self.gathered[k])
             self._H.assemble_tiles(self.gathered[k].data_ptr(), self.w, self.h, self.world, self.frame.data_ptr(),
                                    stream=self.s_comm.cuda_stream)
             self.ev_comm[k].record(self.s_comm)

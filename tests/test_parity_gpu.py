@@ -305,6 +305,35 @@ def test_tile_sharding_assembles_to_full_frame(main_pair, H):
         assert np.array_equal(tiles.assemble_numpy(gathered.cpu().numpy(), W, Hh, world), full)
 
 
+def test_native_rccl_gather_single_rank(main_pair, H):
+    """rrt_comm_* / rrt_gather_tiles (the gather a host without Python calls): what one GPU can check -- RCCL is
+    found and initialised inside librrt.so, a world of one gathers its own tiles (all-gather and gather-to-root),
+    and the frame assembles.  More ranks need more GPUs: the N-rank transport itself is left to multi-GPU runs
+    (bench.py with RRT_BENCH_GATHER=native)."""
+    import torch
+    from rustraytracer_amd import distributed as D
+    g, _ = main_pair
+    W, Hh = 500, 270
+    full = g.render(W, Hh, spp=2, seed=9, want=("rgb",))["rgb"]
+    comm = D.NativeComm(0, 1, torch.device("cuda", 0))
+    try:
+        local, gathered = D.alloc_tile_buffers(W, Hh, 1, torch.device("cuda", 0))
+        st = H.make_settings(W, Hh, spp=2, seed=9, tile_rank=0, tile_world=1)
+        for root in (-1, 0):
+            local.zero_(); gathered.zero_()
+            # tile_world = 1 renders row-major; cut the tiles on the host as the sharded path would produce them
+            from rustraytracer_amd import tiles
+            local.copy_(torch.from_numpy(tiles.extract_rank_tiles(full, 0, 1)).cuda())
+            comm.gather(local, gathered, W, Hh, root=root)
+            out = torch.zeros((Hh, W, 3), dtype=torch.uint8, device="cuda:0")
+            H.assemble_tiles(gathered.data_ptr(), W, Hh, 1, out.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), full), root
+        del st
+    finally:
+        comm.close()
+
+
 def test_cfg2_1080p_16spp_properties(H, scenes, O):
     """BASELINE configs[1] at full size: checked through size-independent
     properties (the oracle covers a strided sample of rows)."""
