@@ -63,7 +63,7 @@ CONFIGS = {
 
 # Algorithmic work per ray for the rooflines -- the constants frozen in BASELINE.md section 3.
 # Bytes are sizes of the device layout (csrc/rrt_device.h); flops are SURVEY 8(d)'s.
-S_NODE, S_LEAF, S_BOX32, S_TRI, S_WIN = 16, 80, 24, 72, 28   # DNodeI / DLeaf / DBox32 / DTri / winner's leaf_ref + normal
+S_NODE, S_LEAF, S_BOX32, S_TRI, S_WIN = 16, 128, 24, 72, 32   # DNodeI / DLeaf / DBox32 / DTri / winner's DRef + normal
 F_TRI, F_BOX, F_NODE, F_SHADE, F_SPHERE = 53, 30, 1, 120, 25
 B_SKY, B_CONT, B_DEAD = 7, 116, 24   # HBM I/O of a primary ray: ends in the sky / continues / extra when its reflection is dead
 PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -191,9 +191,9 @@ def io_bytes_per_ray(stats):
 
 
 def traversal_bytes_per_ray(per):
-    """descent steps x 16 B + leaves x 80 B + listed triangles x 24 B (the cull box the
+    """descent steps x 16 B + leaves x 128 B + listed triangles x 24 B (the cull box the
     kernel reads in place of the triangle) + triangles whose own box the ray crosses x 72 B (the exact test no
-    box cull can avoid) + 28 B for a mesh hit (triangle id + normal)."""
+    box cull can avoid) + 32 B for a mesh hit (triangle id, rank + normal)."""
     return (per["node_steps"] * S_NODE + per["leaf_visits"] * S_LEAF + per["tri_tests"] * S_BOX32
             + per["tri_box_hits"] * S_TRI + per["mesh_hit_fraction"] * S_WIN)
 
@@ -457,7 +457,7 @@ def main():
                     roof.update({"achieved": ach, "frac": ach / PEAK_HBM_GBS, "bytes_per_ray": io_b + tb,
                                  "io_bytes_per_ray": io_b, "traversal_bytes_per_ray": tb, "per_primary_ray": per,
                                  "algorithmic_bytes_per_launch": (io_b + tb) * rays_per_launch,
-                                 "formula": "B_io + N_node*16 + N_leaf*80 + N_tri*24 + N_tri_box_hit*72 + hit*28 (BASELINE.md section 3)"})
+                                 "formula": "B_io + N_node*16 + N_leaf*128 + N_tri*24 + N_tri_box_hit*72 + hit*32 (BASELINE.md section 3)"})
                     fl = flops_per_ray(per)
                     roof["valu_f64"] = {"achieved": fl * rays_per_launch / secs / 1e12, "peak": PEAK_F64_TFLOPS,
                                         "frac": fl * rays_per_launch / secs / 1e12 / PEAK_F64_TFLOPS, "flops_per_ray": fl}

@@ -1474,7 +1474,6 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
 // A bounce level with at most this many rays runs in tail mode (see k_wave_bounce): fewer rays than the chip has
 // wave slots for (256 CUs x 16 waves x 64 lanes = 262 144), so re-queueing them level by level only adds launches.
 constexpr uint32_t kTailRays = 1u << 16;
-constexpr uint32_t kCarryLanes = 0;
 
 // Bounce level `bounce`: the queue is cut into units of 64 rays; block b owns units b, b + grid, ...
 // and its four waves pull them from a counter in LDS.  Rays of a bounce level differ in cost by
@@ -1496,7 +1495,8 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     RRT_LDS uint32_t* next_unit = (RRT_LDS uint32_t*)(smem + lds_layout_bytes(sc));
     if (threadIdx.x == 0) *next_unit = 0u;
     // a block with a single 64-ray unit (the thin last levels) descends from global memory rather than copy the array
-    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, my_units > 1u);   // ends with the barrier that also publishes *next_unit
+    // (a tail-mode unit casts its rays level after level: worth the copy as well)
+    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, my_units > 1u || tail);   // ends with the barrier that also publishes *next_unit
     const uint64_t P = wk.cap;
     double* q = wk.q[bounce & 1];
     const uint32_t lane = threadIdx.x & 63u;
@@ -1537,10 +1537,11 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
         // rays than the chip has lanes) carries every path on to its end in its own lane -- a launch whose rays do not
         // fill the chip lasts as long as its slowest ray, 25-90 us each for the last levels of a frame.  All lanes of a
         // wave sit at the same depth, so the level stays wave-uniform; the rays of the carried levels are counted
-        // where they are cast.  (kCarryLanes > 0 would also let a wave of a THICK level carry on when only a few of
-        // its rays continue; measured with 16 on cfg2: bounce levels 0.375 -> 0.478 ms -- the nearly empty waves hold
-        // their slots for two more casts and the level's other waves lose their latency hiding.  Left at 0.)
-        {
+        // where they are cast.  Two separate call sites on purpose: routed through the carrying loop, the thick levels
+        // spilled 17 VGPRs (72 B of scratch per lane, +330 MB of HBM writes per cfg2 frame) and lost 15 %.  Also
+        // measured and dropped: letting a wave of a THICK level carry on when at most 16 of its rays continue
+        // (cfg2 bounce levels 0.375 -> 0.478 ms: the nearly empty waves hold their slots for two more casts).
+        if (tail) {
             bool act = active;
             for (uint32_t b = bounce;;) {
                 NextRay nx;
@@ -1548,10 +1549,6 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
                 act = act && nx.cont;
                 const unsigned long long going = __ballot(act);
                 if (going == 0ull) break;
-                if (!tail && (uint32_t)__popcll(going) > kCarryLanes) {
-                    enqueue_continuation(wk, b, act, nx.zero_mix, nx.o, nx.d, path, nx.medium);
-                    break;
-                }
                 ++b;
                 if (lane == (uint32_t)(__ffsll((long long)going) - 1)) {
                     const unsigned long long n = (unsigned long long)__popcll(going);
@@ -1560,6 +1557,8 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
                 }
                 o = nx.o; d = nx.d; medium = nx.medium; dead_sky = nx.zero_mix;
             }
+        } else {
+            process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, dead_sky, &tch);
         }
         const unsigned long long t2 = TSTAMP();
         if (__ballot(active && !dead_sky) != 0ull) acc_lc += tch;
