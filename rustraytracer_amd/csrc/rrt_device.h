@@ -208,6 +208,7 @@ struct DFrame {
     uint32_t npx_local;      // n_slots * 256
     uint32_t s0, ns;         // first sample / samples in this batch
     uint32_t tile_skew;      // tile_skew(tiles_x, tile_world): row ty of the tile grid is rotated by tile_skew * ty columns
+    uint32_t pack_log2;      // a wave of the primary kernel = 64 >> pack_log2 pixels x (1 << pack_log2) samples of this batch
 };
 
 // Tile t (t % tile_world = owner, t / tile_world = slot) is the tile in row ty = t / tiles_x of the image, column

@@ -1436,7 +1436,6 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
     const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, true);
     const uint32_t n_chunks = (uint32_t)(((uint64_t)fr.ns * fr.npx_local) >> 8);   // 256 paths per chunk, exact
     const uint32_t n_tiles = fr.npx_local >> 8;
-    const uint32_t my_in = tile_swz(threadIdx.x);   // this thread's pixel inside every tile it visits
 #if RRT_XCD_ORDER
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes the tiles
     // t = x (mod 8), and its blocks walk them tile-major (all samples of a tile back to back, on
@@ -1455,9 +1454,21 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
 #else
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
 #endif
-        // chunk = (sample, tile slot): wave-uniform, so the tile's position is scalar arithmetic
-        const uint32_t path = chunk * 256u + threadIdx.x;
-        const uint32_t s_local = chunk / n_tiles, slot = chunk - s_local * n_tiles;
+        // chunk = (sample, tile slot): wave-uniform, so the tile's position is scalar arithmetic.  With sample
+        // packing (pack_log2 = p > 0) the 2^p chunks of a tile's samples [g 2^p, (g+1) 2^p) trade paths among
+        // themselves: chunk j of them takes pixels [j 256/2^p, (j+1) 256/2^p) of the tile at all 2^p samples, so a wave
+        // is 64/2^p neighbouring pixels x 2^p samples.  Path numbers (and with them every buffer layout and the
+        // order of the sums) stay what they are; only which lane traces which path changes.
+        uint32_t s_local = chunk / n_tiles;
+        const uint32_t slot = chunk - s_local * n_tiles;
+        uint32_t my_t = threadIdx.x;
+        if (fr.pack_log2) {
+            const uint32_t p = fr.pack_log2, sm = (1u << p) - 1u, j = s_local & sm;
+            s_local = (s_local & ~sm) | (threadIdx.x & sm);
+            my_t = (j << (8u - p)) | (threadIdx.x >> p);
+        }
+        const uint32_t my_in = tile_swz(my_t);
+        const uint32_t path = (s_local * n_tiles + slot) * 256u + my_t;
         const uint32_t tile = slot * fr.tile_world + fr.tile_rank;
         const uint32_t ty = tile / fr.tiles_x;
         uint32_t tx = tile - ty * fr.tiles_x;
