@@ -1182,6 +1182,25 @@ __host__ __device__ inline uint32_t tile_unswz(uint32_t in) {     // storage ord
 // path-order local pixel index (what samp/records/queues are indexed by) -> storage-order index
 RRT_DEV uint32_t path_to_lp(uint32_t pp) { return (pp & ~255u) | tile_swz(pp & 255u); }
 
+// Path numbers under sample packing (DFrame::pack_log2 = p, S = 2^p).  A chunk of 256 consecutive path numbers is
+// what one block iteration of the primary kernel traces, lane t = path & 255: without packing (p = 0) all 256 pixels
+// of tile slot `slot` at sample `sc` (chunk = sc * n_tiles + slot).  With packing the S chunks (g S + j, slot),
+// j < S, cover the same S x 256 paths differently: chunk j holds pixels t' in [j 256/S, (j+1) 256/S) of the tile at
+// the S samples g S + (t & (S-1)), t' = j 256/S + (t >> p) -- a wave is 64/S neighbouring pixels at S samples, and its
+// 64 records, queue entries and samples are neighbours in memory.
+RRT_DEV uint32_t path_of(const DFrame& fr, uint32_t s_local, uint32_t pp) {        // pp = slot * 256 + t'
+    const uint32_t p = fr.pack_log2, sm = (1u << p) - 1u, n_tiles = fr.npx_local >> 8;
+    const uint32_t tp = pp & 255u, slot = pp >> 8, j = tp >> (8u - p);
+    const uint32_t t = ((tp & ((1u << (8u - p)) - 1u)) << p) | (s_local & sm);
+    return ((((s_local & ~sm) | j) * n_tiles + slot) << 8) | t;
+}
+RRT_DEV void path_decode(const DFrame& fr, uint32_t path, uint32_t* s_local, uint32_t* pp) {
+    const uint32_t p = fr.pack_log2, sm = (1u << p) - 1u, n_tiles = fr.npx_local >> 8;
+    const uint32_t chunk = path >> 8, t = path & 255u, sc = chunk / n_tiles, slot = chunk - sc * n_tiles;
+    *s_local = (sc & ~sm) | (t & sm);
+    *pp = (slot << 8) | ((sc & sm) << (8u - p)) | (t >> p);
+}
+
 RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y) {
     const uint32_t slot = lp >> 8, in = lp & 255u;
     const uint32_t tile = slot * fr.tile_world + fr.tile_rank;
@@ -1225,9 +1244,11 @@ struct NextRay {
 template <bool PRIMARY, int CULL, bool GROUPS, bool PL, class LDS>
 RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFrame& fr, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
-                         uint32_t pixel, uint32_t sample, bool dead_sky = false, unsigned long long* tacc = nullptr,
-                         NextRay* next = nullptr) {
+                         uint32_t pixel, uint32_t sample, uint32_t tag_base, bool dead_sky = false,
+                         unsigned long long* tacc = nullptr, NextRay* next = nullptr) {
     const uint64_t P = wk.cap;
+    const uint32_t tag_off = path * 4u;
+    (void)tag_base;
     const uint32_t rec_off = path * (uint32_t)(kRecDoubles * 8);
     const bool aov = sample == 0u;
     bool cont = false, compact = false, zero_mix = false;
@@ -1269,9 +1290,9 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
                 if (!PRIMARY && m.lobe == 2) {
                     // the RNG stream of the diffuse lobe is keyed by the global pixel and sample of the path
                     // (two integer divisions per lane: only paid by the rays that draw from it)
-                    const uint32_t s_local = path / fr.npx_local;
-                    uint32_t x = 0, y = 0;
-                    local_pixel(fr, path_to_lp(path - s_local * fr.npx_local), &x, &y);
+                    uint32_t s_local, pp, x = 0, y = 0;
+                    path_decode(fr, path, &s_local, &pp);
+                    local_pixel(fr, path_to_lp(pp), &x, &y);
                     kp = y * fr.width + x;
                     ks = fr.s0 + s_local;
                 }
@@ -1284,7 +1305,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             // texel bytes ARE the colour -- 4 bytes go to samp32 instead of 24 to samp, and k_accumulate
             // looks the quotients up.
             CNT(8);
-            at_off<uint32_t>(wk.samp32, path * 4u) = kSampTexel | sky_texel(sc, lds, d);
+            at_off<uint32_t>(wk.samp32, tag_off) = kSampTexel | sky_texel(sc, lds, d);
             compact = true;
         } else {
             // A bounce ray that leaves the scene ends its path (most do).  Its innermost enclosing
@@ -1306,7 +1327,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             fold_from = k;
             }
         }
-        if (PRIMARY && !compact) at_off<uint32_t>(wk.samp32, path * 4u) = 0u;   // "see samp" (written now or by a bounce level)
+        if (PRIMARY && !compact) at_off<uint32_t>(wk.samp32, tag_off) = 0u;   // "see samp" (written now or by a bounce level)
         if (!cont && !compact) {
             CNT(10);
             // fold the enclosing casts: final = (A + R*mixR) + Pm  (tracer.rs:194-202)
@@ -1454,21 +1475,20 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
 #else
     for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
 #endif
-        // chunk = (sample, tile slot): wave-uniform, so the tile's position is scalar arithmetic.  With sample
-        // packing (pack_log2 = p > 0) the 2^p chunks of a tile's samples [g 2^p, (g+1) 2^p) trade paths among
-        // themselves: chunk j of them takes pixels [j 256/2^p, (j+1) 256/2^p) of the tile at all 2^p samples, so a wave
-        // is 64/2^p neighbouring pixels x 2^p samples.  Path numbers (and with them every buffer layout and the
-        // order of the sums) stay what they are; only which lane traces which path changes.
+        // chunk = (sample, tile slot), or with sample packing (sample group and part of the tile, tile slot): see
+        // path_of.  Wave-uniform, so the tile's position is scalar arithmetic.
+        const uint32_t path = chunk * 256u + threadIdx.x;
         uint32_t s_local = chunk / n_tiles;
         const uint32_t slot = chunk - s_local * n_tiles;
         uint32_t my_t = threadIdx.x;
+        uint32_t tag_base = s_local * fr.npx_local + (slot << 8);
         if (fr.pack_log2) {
-            const uint32_t p = fr.pack_log2, sm = (1u << p) - 1u, j = s_local & sm;
+            const uint32_t p = fr.pack_log2, sm = (1u << p) - 1u;
+            tag_base = (s_local & ~sm) * fr.npx_local + (slot << 8) + ((s_local & sm) << (8u - p));
+            my_t = ((s_local & sm) << (8u - p)) | (threadIdx.x >> p);
             s_local = (s_local & ~sm) | (threadIdx.x & sm);
-            my_t = (j << (8u - p)) | (threadIdx.x >> p);
         }
         const uint32_t my_in = tile_swz(my_t);
-        const uint32_t path = (s_local * n_tiles + slot) * 256u + my_t;
         const uint32_t tile = slot * fr.tile_world + fr.tile_rank;
         const uint32_t ty = tile / fr.tiles_x;
         uint32_t tx = tile - ty * fr.tiles_x;
@@ -1478,7 +1498,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         const uint32_t sample = fr.s0 + s_local;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         if (active) primary_ray(fr, lds, x, y, sample, &o, &d);
-        process_ray<true, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample);
+        process_ray<true, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample, tag_base);
     }
 }
 
@@ -1556,7 +1576,7 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
             bool act = active;
             for (uint32_t b = bounce;;) {
                 NextRay nx;
-                process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, act, path, o, d, medium, b, nullptr, nullptr, 0u, 0u, dead_sky, &tch, &nx);
+                process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, act, path, o, d, medium, b, nullptr, nullptr, 0u, 0u, 0u, dead_sky, &tch, &nx);
                 act = act && nx.cont;
                 const unsigned long long going = __ballot(act);
                 if (going == 0ull) break;
@@ -1569,7 +1589,7 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
                 o = nx.o; d = nx.d; medium = nx.medium; dead_sky = nx.zero_mix;
             }
         } else {
-            process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, dead_sky, &tch);
+            process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, 0u, dead_sky, &tch);
         }
         const unsigned long long t2 = TSTAMP();
         if (__ballot(active && !dead_sky) != 0ull) acc_lc += tch;
@@ -1597,6 +1617,45 @@ RRT_DEV void resolve_pixel(const DFrame& fr, uint32_t lp, V3 sum, uint8_t* d_rgb
     }
 }
 
+// One trip of k_accumulate: samples s0 .. s0 + TRIP - 1 of pixel pp.  Their tags, then the colours the tags point to,
+// are requested together (the kernel is a latency chain tag -> colour per sample otherwise); the sum stays in sample
+// order.  PACKED (sample packing with at least TRIP samples a wave): the path numbers of these samples are
+// consecutive (path_of) and ns is a multiple of TRIP, so a lane reads TRIP * 4 B of tags and up to TRIP * 24 B of
+// colours in one piece -- with TRIP = 16 whole cache lines that no other lane shares, each fetched once.
+template <uint32_t TRIP, bool PACKED>
+RRT_DEV void accumulate_trip(const DWork& wk, const DFrame& fr, const double* by255, uint32_t s0, uint32_t pp, V3* acc) {
+    uint32_t tag[TRIP];
+    V3 c[TRIP];
+    const uint32_t p0 = path_of(fr, s0, pp);
+    if (PACKED) {
+#pragma unroll
+        for (uint32_t j = 0; j < TRIP; j += 4u) {
+            const uint4 tg = *(const uint4*)(wk.samp32 + p0 + j);
+            tag[j] = tg.x; tag[j + 1] = tg.y; tag[j + 2] = tg.z; tag[j + 3] = tg.w;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < TRIP; ++j) {
+            const uint32_t s = s0 + j < fr.ns ? s0 + j : fr.ns - 1u;     // clamped: re-reads the last sample, not added
+            tag[j] = wk.samp32[path_of(fr, s, pp)];
+        }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < TRIP; ++j) {
+        const uint32_t s = s0 + j < fr.ns ? s0 + j : fr.ns - 1u;
+        const size_t p = 3 * (size_t)(PACKED ? p0 + j : path_of(fr, s, pp));
+        c[j] = mk(0., 0., 0.);
+        if (!(tag[j] & kSampTexel)) c[j] = mk(wk.samp[p], wk.samp[p + 1], wk.samp[p + 2]);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < TRIP; ++j) {
+        if (!PACKED && s0 + j >= fr.ns) break;
+        const uint32_t t = tag[j];
+        const V3 v = (t & kSampTexel) ? mk(by255[t & 255u], by255[(t >> 8) & 255u], by255[(t >> 16) & 255u]) : c[j];
+        *acc = (fr.s0 + s0 + j == 0u) ? v : *acc + v;
+    }
+}
+
 // accum[lp] (+)= sum over this batch's samples, in sample order (deterministic: the oracle's loop).
 // FINAL (the frame's last batch): the sum goes straight into the pixel instead of back to accum.
 template <bool FINAL>
@@ -1609,30 +1668,12 @@ __global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr, uint8_t
     const uint32_t pp = (lp & ~255u) | tile_unswz(lp & 255u);   // where the trace kernels put this pixel's samples
     V3 acc = mk(0., 0., 0.);
     if (fr.s0 != 0u) acc = mk(wk.accum[lp], wk.accum[lp + N], wk.accum[lp + 2 * (size_t)N]);
-    // four samples per trip: their tags, then the colours the tags point to, are requested together
-    // (the kernel is a latency chain tag -> colour per sample otherwise); the sum stays in sample order
-    for (uint32_t s0 = 0; s0 < fr.ns; s0 += 4u) {
-        uint32_t tag[4];
-        V3 c[4];
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
-            const uint32_t s = s0 + j < fr.ns ? s0 + j : fr.ns - 1u;     // clamped: re-reads the last sample, not added
-            tag[j] = wk.samp32[(size_t)s * N + pp];
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
-            const uint32_t s = s0 + j < fr.ns ? s0 + j : fr.ns - 1u;
-            const size_t p = 3 * ((size_t)s * N + pp);
-            c[j] = mk(0., 0., 0.);
-            if (!(tag[j] & kSampTexel)) c[j] = mk(wk.samp[p], wk.samp[p + 1], wk.samp[p + 2]);
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < 4u; ++j) {
-            if (s0 + j >= fr.ns) break;
-            const uint32_t t = tag[j];
-            const V3 v = (t & kSampTexel) ? mk(by255[t & 255u], by255[(t >> 8) & 255u], by255[(t >> 16) & 255u]) : c[j];
-            acc = (fr.s0 + s0 + j == 0u) ? v : acc + v;
-        }
+    if (fr.pack_log2 >= 4u) {
+        for (uint32_t s0 = 0; s0 < fr.ns; s0 += 16u) accumulate_trip<16, true>(wk, fr, by255, s0, pp, &acc);
+    } else if (fr.pack_log2 >= 2u) {
+        for (uint32_t s0 = 0; s0 < fr.ns; s0 += 4u) accumulate_trip<4, true>(wk, fr, by255, s0, pp, &acc);
+    } else {
+        for (uint32_t s0 = 0; s0 < fr.ns; s0 += 4u) accumulate_trip<4, false>(wk, fr, by255, s0, pp, &acc);
     }
     if (FINAL) {
         resolve_pixel(fr, lp, acc, d_rgb8, d_color);
