@@ -21,7 +21,7 @@ north_star's target frame: the same scene at 1920x1080, 64 spp IN TOTAL whatever
 N is; the image's 32x8 tiles are dealt round-robin over the ranks, each renders
 its tiles at 64 spp, one all-gather of the compact RGB8 tile buffers (6.2 MB in
 total) and a de-interleave end the step; the gather of frame i overlaps the
-render of frame i+1 (second stream, double-buffered tile buffers).  The weak
+render of the next frames (own stream, one tile buffer per frame in flight).  The weak
 figure (16*N spp, one 1080p/16spp frame of samples per GPU) is measured in the
 same run and printed beside it (`weak`); `--scaling weak` swaps the two.
 
@@ -29,6 +29,12 @@ Metric: Mrays/s, whole job.  A ray = one world-level closest-hit query (one
 `RayTracer::cast`, src/tracer.rs:177) actually executed on the GPU, with
 reference semantics (prune_zero_mix = 0: the reflection ray is cast even when
 its mix is 0.0, as src/tracer.rs:195-201 does).
+
+Frames in flight: steps are enqueued round-robin on `--in-flight` streams (default 3; the scene keeps one set of work
+buffers per stream), so the thin tail of one frame's launch chain (bounce levels, accumulate) runs under the next
+frame's primary kernel.  Every step is a complete frame; `value` is the throughput of K of them.  The figure with one
+frame at a time (the latency of a frame) is printed beside it (`one_frame_at_a_time`), and the per-kernel durations
+of the roofline come from that sequential pass.
 
 Timing: W warm-up steps, then blocks of exactly K steps, each bracketed by a
 barrier + torch.cuda.synchronize() on both sides and reduced with MAX over the
@@ -88,6 +94,8 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel")
     ap.add_argument("--budget-gib", type=float, default=0.0, help="work-buffer budget in GiB (0 = library default)")
     ap.add_argument("--cull-mode", type=int, default=-1, help="rrt_set_cull_mode (0 off, 1 on, 2 verify; -1 = library default)")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("RRT_FRAMES_IN_FLIGHT", "3")),
+                    help="frames in flight (one stream and one set of work buffers each); 1 = one frame at a time")
     return ap.parse_args()
 
 
@@ -263,31 +271,37 @@ def main():
     scene.commit()                                   # scene resident in HBM before timing
 
     frame = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+    depth = max(1, min(args.in_flight, 4))
+    frames = [frame] + [torch.empty_like(frame) for _ in range(depth - 1)] if world == 1 else [frame]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
     # RRT_BENCH_GATHER=native: the gather goes through librrt.so's own RCCL communicator (rrt_comm_*, the path of
     # a host without Python) instead of torch.distributed's; torch's group still carries the id and the barriers
     native = D.NativeComm(rank, world, dev) if world > 1 and os.environ.get("RRT_BENCH_GATHER", "torch") == "native" else None
-    pipe = D.TilePipeline(scene, w, h, world, dev, frame, native=native) if world > 1 else None
-    if world > 1:
-        scene.set_timing(0)      # no hipEvents between the launches of a rank's sub-millisecond frames (N = 1 keeps them:
-                                 # the roofline needs the primary kernel's live duration)
+    pipe = D.TilePipeline(scene, w, h, world, dev, frame, native=native, depth=depth) if world > 1 else None
+    scene.set_timing(0)          # no hipEvents between the launches of the timed frames (the sequential pass for the
+                                 # roofline turns them on)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(spp_total):
+    def measure(spp_total, in_flight):
         """-> (list of block seconds [max over ranks], stats of this rank's last frame)"""
         st = Hst.make_settings(w, h, spp=spp_total, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune,
                                tile_rank=rank, tile_world=world, batch_spp=args.batch_spp)
 
+        count = [0]
+
         def step():
             if world == 1:
-                scene.render_device(st, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+                k = count[0] % in_flight
+                count[0] += 1
+                scene.render_device(st, frames[k].data_ptr(), stream=streams[k].cuda_stream)
             else:
                 pipe.step(st)
 
-        for _ in range(args.warmup):
+        for _ in range(max(args.warmup, in_flight)):
             step()
         blocks, total = [], 0.0
         while True:
@@ -306,8 +320,8 @@ def main():
                 break
         return blocks, scene.stats()
 
-    def figure(spp_total):
-        blocks, stats = measure(spp_total)
+    def figure(spp_total, in_flight=depth):
+        blocks, stats = measure(spp_total, in_flight)
         rays_step, paths_step, overflow = D.sum_over_ranks(
             [stats["rays_traced"], stats["paths"], stats["traversal_overflow"]], dev)
         med = median(blocks)
@@ -318,9 +332,14 @@ def main():
                            "ms_per_step_max": max(blocks) / args.steps * 1e3}}, stats
 
     other = None
+    sequential = None
     if world == 1:
         main_fig, stats = figure(spp0)
         scaling = "strong"                    # one GPU: the distinction is empty; N > 1 defaults to strong
+        if depth > 1:
+            scene.set_timing(2)               # per-kernel events: this pass feeds the roofline
+            sequential, stats = figure(spp0, 1)
+            scene.set_timing(0)
     else:
         spp_strong, spp_weak = (STRONG_SPP if args.config == "cfg2" and not args.spp else spp0), spp0 * world
         strong, stats_s = figure(spp_strong)
@@ -345,6 +364,7 @@ def main():
             B.check(B.lib.rrt_render(scene.h, C.byref(cam), C.byref(st), rgb.ctypes.data_as(C.c_void_p), None, None, None))
         host_ms = (time.perf_counter() - th) / n_host * 1e3
         # restore the stats of a device frame (rrt_render overwrote them with identical counters; timings differ)
+        scene.set_timing(2)
         scene.render_device(st, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         stats = scene.stats()
@@ -354,27 +374,27 @@ def main():
         # Strong-scaling rehearsal on one GPU (no 8-GPU node is guaranteed): the target frame (1080p, 64 spp) as the
         # 8 ranks of tile_world = 8 would each render it, one after the other on this GPU.  max_r T(r) against
         # T(full) / 8 = load balance + fixed per-frame cost, everything but the gather itself.
-        def frame_ms(tile_rank, tile_world, out_ptr):
+        def frame_ms(tile_rank, tile_world, outs):
             st = Hst.make_settings(w, h, spp=STRONG_SPP, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune,
                                    tile_rank=tile_rank, tile_world=tile_world)
-            n = 10
+            n = 12
             ts = []
             for rep in range(4):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(n):
-                    scene.render_device(st, out_ptr, stream=torch.cuda.current_stream().cuda_stream)
+                for i in range(n):
+                    scene.render_device(st, outs[i % depth].data_ptr(), stream=streams[i % depth].cuda_stream)
                 torch.cuda.synchronize()
                 ts.append((time.perf_counter() - t0) / n * 1e3)
             return median(ts[1:])
         scene.set_timing(0)      # as the N-rank path runs it
-        t_full = frame_ms(0, 1, frame.data_ptr())
-        local, _g = D.alloc_tile_buffers(w, h, 8, dev)
-        t_rank = [frame_ms(r, 8, local.data_ptr()) for r in range(8)]
-        rank_share = {"tile_world": 8, "spp_total": STRONG_SPP, "t_full_ms": t_full, "t_rank_ms": t_rank,
+        t_full = frame_ms(0, 1, frames)
+        locals_ = [D.alloc_tile_buffers(w, h, 8, dev)[0] for _ in range(depth)]
+        t_rank = [frame_ms(r, 8, locals_) for r in range(8)]
+        rank_share = {"tile_world": 8, "spp_total": STRONG_SPP, "frames_in_flight": depth, "t_full_ms": t_full, "t_rank_ms": t_rank,
                       "rank_share_efficiency": (t_full / 8.0) / max(t_rank),
-                      "what": "T(full)/8 over max_r T(rank r of 8), each measured alone on this one GPU, host-timed with a "
-                              "device sync around 10 frames; excludes the RCCL gather (0.78 MB per rank)"}
+                      "what": "T(full)/8 over max_r T(rank r of 8), each measured alone on this one GPU with the bench's frames in "
+                              "flight, host-timed with a device sync around 12 frames; excludes the RCCL gather (0.78 MB per rank)"}
         # leave the work buffers sized for the bench frame again
         scene.set_timing(2)
         st = Hst.make_settings(w, h, spp=spp0, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune, batch_spp=args.batch_spp)
@@ -406,6 +426,11 @@ def main():
                        "parallelism": "tiles%d" % world, "traversal_overflow": main_fig["traversal_overflow"],
                        "n_batches": stats["n_batches"], "level_rays": stats["level_rays"]},
         }
+        line["config"]["frames_in_flight"] = depth
+        if sequential is not None:
+            line["one_frame_at_a_time"] = {"value": sequential["value"], "ms_per_step": sequential["ms_per_step"],
+                                           "timing": sequential["timing"],
+                                           "what": "the same K steps with one frame in flight (per-kernel hipEvents on): a frame's latency"}
         if other is not None:
             line["weak" if scaling == "strong" else "strong"] = {
                 "value": other["value"], "ms_per_step": other["ms_per_step"], "spp_total": other["spp_total"],

@@ -244,7 +244,14 @@ int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint
 /* Same with DEVICE output pointers, asynchronous on `stream` (a hipStream_t,
  * NULL = default stream).  With tile_world > 1 d_rgb8 is this rank's compact
  * tile buffer [rrt_tile_slots()][RRT_TILE_H][RRT_TILE_W][3] (slot j = tile
- * j*tile_world + tile_rank) and the AOV pointers must be NULL. */
+ * j*tile_world + tile_rank) and the AOV pointers must be NULL.
+ * Frames in flight: the scene keeps one set of work buffers (ray queues, level records, samples; each up to
+ * the work budget) per stream it has rendered on, at most 8.  Calls on ONE stream are ordered by it; calls on
+ * DIFFERENT streams may overlap on the GPU -- the thin end of one frame's launch chain (bounce levels,
+ * accumulate) then runs under the next frame's primary kernel: measured 1.76 -> 1.49 ms per 1080p/16spp frame
+ * with three streams, 1.02 -> 0.75 ms for one rank's eighth of the 64-spp frame.  A ninth stream returns
+ * RRT_E_STATE.  rrt_get_stats reports the frame enqueued last.  Do not change or re-commit the scene while
+ * frames are in flight. */
 int rrt_render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids,
                       void* d_t, void* d_color, void* stream);
 

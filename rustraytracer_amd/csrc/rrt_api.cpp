@@ -101,6 +101,29 @@ struct TimedLaunch {
     uint32_t launches = 1;   // kernel launches between a and b
 };
 
+struct WorkSet {
+    hipStream_t stream = nullptr;
+    DevBuf w_q[2], w_qcount, w_rec, w_samp, w_samp32, w_accum, w_stats;
+    // timing and counters of the last frame rendered with this set
+    std::vector<TimedLaunch> timed;
+    size_t timed_used = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    bool frame_timed = false;                   // the last frame recorded events (the no-alloc entry point does not)
+    const unsigned long long* stats_src = nullptr;   // device counters of the last frame (w_stats or the static scratch)
+    rrt_stats stats{};
+    WorkSet() = default;
+    WorkSet(const WorkSet&) = delete;
+    WorkSet& operator=(const WorkSet&) = delete;
+    ~WorkSet() {
+        for (auto& t : timed) {
+            if (t.a) (void)hipEventDestroy(t.a);
+            if (t.b) (void)hipEventDestroy(t.b);
+        }
+        if (ev_begin) (void)hipEventDestroy(ev_begin);
+        if (ev_end) (void)hipEventDestroy(ev_end);
+    }
+};
+
 }  // namespace
 
 namespace rrt {
@@ -129,28 +152,33 @@ struct rrt_scene {
     DevBuf d_ents, d_spheres, d_meshes, d_mats, d_groups, d_plights, d_mesh_stage;
     rrt::DScene dscene{};
 
-    // work buffers
-    DevBuf w_q[2], w_qcount, w_rec, w_samp, w_samp32, w_accum, w_stats;
     DevBuf w_ids, w_t, w_color, w_rgb;  // staging for the host-output render
 
-    // timing of the last render
-    std::vector<TimedLaunch> timed;
-    size_t timed_used = 0;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    bool have_frame = false;
-    bool frame_timed = false;                   // the last frame recorded events (the no-alloc entry point does not)
-    const unsigned long long* stats_src = nullptr;   // device counters of the last frame (w_stats or the static scratch)
-    rrt_stats stats{};
-
-    ~rrt_scene() {
-        for (auto& t : timed) {
-            if (t.a) (void)hipEventDestroy(t.a);
-            if (t.b) (void)hipEventDestroy(t.b);
-        }
-        if (ev_begin) (void)hipEventDestroy(ev_begin);
-        if (ev_end) (void)hipEventDestroy(ev_end);
-    }
+    // Work buffers and the record of the last frame, one set per stream the caller renders on: frames on different
+    // streams may be in flight together (each has its own queues, records and samples; the scene is read-only to
+    // them), frames on one stream are ordered by it and share a set.
+    std::vector<std::unique_ptr<WorkSet>> sets;
+    WorkSet noalloc_set;            // rrt_render_device_noalloc: no buffers of its own (the static scratch), no events
+    WorkSet* last = nullptr;        // what rrt_get_stats reports
 };
+
+namespace {
+
+constexpr size_t kMaxWorkSets = 8;
+
+// The work set of `stream` (created on first use; at most kMaxWorkSets streams per scene).
+int work_set_for(rrt_scene* s, hipStream_t stream, WorkSet** out) {
+    for (auto& w : s->sets)
+        if (w->stream == stream) { *out = w.get(); return RRT_OK; }
+    if (s->sets.size() >= kMaxWorkSets)
+        return fail(RRT_E_STATE, "a scene renders on at most " + std::to_string(kMaxWorkSets) + " different streams (one set of work buffers each)");
+    s->sets.emplace_back(new WorkSet);
+    s->sets.back()->stream = stream;
+    *out = s->sets.back().get();
+    return RRT_OK;
+}
+
+}  // namespace
 
 namespace {
 
@@ -563,7 +591,7 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
     return RRT_OK;
 }
 
-int ensure_work(rrt_scene* s, const FramePlan& pl, rrt::DWork* wk) {
+int ensure_work(WorkSet* s, const FramePlan& pl, rrt::DWork* wk) {
     const uint64_t P = pl.cap;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(s->w_q[i].ensure(P * rrt::kRecDoubles * 8));
@@ -618,7 +646,7 @@ int carve_work(unsigned char* base, uint64_t bytes, const FramePlan& pl, rrt::DW
     return RRT_OK;
 }
 
-int timed_slot(rrt_scene* s, TimedLaunch** out) {
+int timed_slot(WorkSet* s, TimedLaunch** out) {
     if (s->timed_used == s->timed.size()) {
         TimedLaunch t;
         HIP_TRY(hipEventCreate(&t.a));
@@ -648,6 +676,8 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     if (st->tile_world > 1 && (d_ids || d_t || d_color))
         return fail(RRT_E_INVALID, "AOV / f64 colour outputs need tile_world == 1");
     rrt::DWork wk{};
+    hipStream_t stream = (hipStream_t)stream_v;
+    WorkSet* ws = &s->noalloc_set;
     if (NOALLOC) {
         if (s->dirty) return fail(RRT_E_STATE, "rrt_render_device_noalloc needs a committed scene (rrt_scene_commit uploads, i.e. allocates)");
         HIP_TRY(hipSetDevice(s->device));
@@ -659,19 +689,20 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     } else {
         rc = commit(s);
         if (rc) return rc;
-        rc = ensure_work(s, pl, &wk);
+        rc = work_set_for(s, stream, &ws);
+        if (rc) return rc;
+        rc = ensure_work(ws, pl, &wk);
         if (rc) return rc;
     }
-    hipStream_t stream = (hipStream_t)stream_v;
     const bool timed = !NOALLOC && s->timing >= 1, timed_kernels = !NOALLOC && s->timing >= 2;
-    if (timed && !s->ev_begin) {
-        HIP_TRY(hipEventCreate(&s->ev_begin));
-        HIP_TRY(hipEventCreate(&s->ev_end));
+    if (timed && !ws->ev_begin) {
+        HIP_TRY(hipEventCreate(&ws->ev_begin));
+        HIP_TRY(hipEventCreate(&ws->ev_end));
     }
-    s->timed_used = 0;
-    s->frame_timed = timed;
-    s->stats_src = wk.stats;
-    if (timed) HIP_TRY(hipEventRecord(s->ev_begin, stream));
+    ws->timed_used = 0;
+    ws->frame_timed = timed;
+    ws->stats_src = wk.stats;
+    if (timed) HIP_TRY(hipEventRecord(ws->ev_begin, stream));
     HIP_TRY(hipMemsetAsync(wk.stats, 0, 8 * 8, stream));
     rrt::DFrame fr = pl.fr;
     for (uint32_t b = 0; b < pl.n_batches; ++b) {
@@ -681,7 +712,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         HIP_TRY(hipMemsetAsync(wk.q_count, 0, 2 * (rrt::kMaxLevels + 1) * 4, stream));
         TimedLaunch* tl = nullptr;
         if (timed_kernels) {
-            rc = timed_slot(s, &tl);
+            rc = timed_slot(ws, &tl);
             if (rc) return rc;
             tl->primary = true;
             tl->launches = 1;
@@ -692,7 +723,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
             HIP_TRY(hipEventRecord(tl->b, stream));
             // one event pair around the batch's bounce levels together (each hipEventRecord between two
             // launches costs ~3 us of idle GPU: ten events a frame were 1.5 % of it)
-            rc = timed_slot(s, &tl);
+            rc = timed_slot(ws, &tl);
             if (rc) return rc;
             tl->primary = false;
             tl->launches = st->max_bounce + 1;
@@ -703,13 +734,13 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         if (timed_kernels) HIP_TRY(hipEventRecord(tl->b, stream));
         rrt::launch_accumulate(wk, fr, b + 1 == pl.n_batches, (uint8_t*)d_rgb8, (double*)d_color, stream);   // the last one resolves
     }
-    if (timed) HIP_TRY(hipEventRecord(s->ev_end, stream));
+    if (timed) HIP_TRY(hipEventRecord(ws->ev_end, stream));
     HIP_TRY(hipGetLastError());
-    s->have_frame = true;
-    s->stats = rrt_stats{};
-    s->stats.paths = pl.valid_px * st->spp;
-    s->stats.primary_rays = s->stats.paths;
-    s->stats.n_batches = pl.n_batches;
+    s->last = ws;
+    ws->stats = rrt_stats{};
+    ws->stats.paths = pl.valid_px * st->spp;
+    ws->stats.primary_rays = ws->stats.paths;
+    ws->stats.n_batches = pl.n_batches;
     return RRT_OK;
 }
 
@@ -1148,37 +1179,38 @@ int rrt_cast_rays(rrt_scene* s, const double* rays, int64_t n, uint32_t max_boun
 int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) try {
     rrt_scene* s = const_cast<rrt_scene*>(cs);
     if (!s || !out) return fail(RRT_E_INVALID, "null argument");
-    if (!s->have_frame) return fail(RRT_E_STATE, "no frame rendered yet");
+    if (!s->last) return fail(RRT_E_STATE, "no frame rendered yet");
     HIP_TRY(hipSetDevice(s->device));
+    WorkSet* ws = s->last;     // the frame enqueued last (on whichever stream)
     float ms = 0.f;
-    if (s->frame_timed) {
-        HIP_TRY(hipEventSynchronize(s->ev_end));
-        HIP_TRY(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
+    if (ws->frame_timed) {
+        HIP_TRY(hipEventSynchronize(ws->ev_end));
+        HIP_TRY(hipEventElapsedTime(&ms, ws->ev_begin, ws->ev_end));
     } else {
         HIP_TRY(hipDeviceSynchronize());   // an untimed (no-alloc) frame: wait for its stream the blunt way
     }
-    s->stats.gpu_ms = ms;
+    ws->stats.gpu_ms = ms;
     double prim = 0.0, bnc = 0.0;
     uint32_t nprim = 0, nbnc = 0;
-    for (size_t i = 0; i < s->timed_used; ++i) {
+    for (size_t i = 0; i < ws->timed_used; ++i) {
         float k = 0.f;
-        HIP_TRY(hipEventElapsedTime(&k, s->timed[i].a, s->timed[i].b));
-        if (s->timed[i].primary) { prim += k; nprim += s->timed[i].launches; }
-        else { bnc += k; nbnc += s->timed[i].launches; }
+        HIP_TRY(hipEventElapsedTime(&k, ws->timed[i].a, ws->timed[i].b));
+        if (ws->timed[i].primary) { prim += k; nprim += ws->timed[i].launches; }
+        else { bnc += k; nbnc += ws->timed[i].launches; }
     }
-    s->stats.primary_kernel_ms = prim;
-    s->stats.bounce_kernel_ms = bnc;
-    s->stats.primary_kernel_launches = nprim;
-    s->stats.bounce_kernel_launches = nbnc;
+    ws->stats.primary_kernel_ms = prim;
+    ws->stats.bounce_kernel_ms = bnc;
+    ws->stats.primary_kernel_launches = nprim;
+    ws->stats.bounce_kernel_launches = nbnc;
     unsigned long long dev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(dev, s->stats_src, sizeof(dev), hipMemcpyDeviceToHost));
-    s->stats.rays_traced = s->stats.primary_rays + dev[0];
-    s->stats.traversal_overflow = dev[1];
-    s->stats.cull_violations = dev[2];
-    s->stats.zero_mix_paths = dev[3];
-    s->stats.level_rays[0] = s->stats.primary_rays;
-    for (int l = 1; l < 4; ++l) s->stats.level_rays[l] = dev[4 + l];
-    *out = s->stats;
+    HIP_TRY(hipMemcpy(dev, ws->stats_src, sizeof(dev), hipMemcpyDeviceToHost));
+    ws->stats.rays_traced = ws->stats.primary_rays + dev[0];
+    ws->stats.traversal_overflow = dev[1];
+    ws->stats.cull_violations = dev[2];
+    ws->stats.zero_mix_paths = dev[3];
+    ws->stats.level_rays[0] = ws->stats.primary_rays;
+    for (int l = 1; l < 4; ++l) ws->stats.level_rays[l] = dev[4 + l];
+    *out = ws->stats;
     return RRT_OK;
 } catch (...) {
     return on_exception();

@@ -76,34 +76,36 @@ def gather_tiles(local, gathered):
 
 
 class TilePipeline:
-    """One frame per step() on this rank: render its tiles, all-gather, de-interleave -- with the
-    exchange of frame i overlapped with the render of frame i+1.  Renders run back to back on one
-    stream (they share the scene's work buffers, so they must not overlap each other); the gather
-    and the de-interleave of a frame run on a second stream behind an event; the tile buffers are
-    double-buffered so that render i+1 never writes what gather i still reads."""
+    """One frame per step() on this rank: render its tiles, all-gather, de-interleave -- with `depth` frames in
+    flight.  Frame i renders on stream i % depth into tile buffer i % depth (the scene keeps one set of work buffers
+    per stream, so renders on different streams overlap: the thin tail of one frame's launch chain runs under the
+    next frame's primary kernel); the gather and the de-interleave of the frames run, in frame order, on one
+    communication stream behind an event; render i waits for gather i - depth to have read its tile buffer."""
 
-    def __init__(self, scene, width, height, world, device, frame, native=None):
+    def __init__(self, scene, width, height, world, device, frame, native=None, depth=3):
         from . import host as H
         self.native = native          # a NativeComm: gather to rank 0 through librrt.so's own RCCL calls
         self._H = H
         self.scene, self.w, self.h, self.world, self.frame = scene, width, height, world, frame
+        self.depth = depth
         self.local, self.gathered = [], []
-        for _ in range(2):
+        for _ in range(depth):
             lo, ga = alloc_tile_buffers(width, height, world, device)
             self.local.append(lo)
             self.gathered.append(ga)
-        self.s_render = torch.cuda.Stream(device=device)
+        self.s_render = [torch.cuda.Stream(device=device) for _ in range(depth)]
         self.s_comm = torch.cuda.Stream(device=device)
-        self.ev_render = [torch.cuda.Event(), torch.cuda.Event()]
-        self.ev_comm = [torch.cuda.Event(), torch.cuda.Event()]
+        self.ev_render = [torch.cuda.Event() for _ in range(depth)]
+        self.ev_comm = [torch.cuda.Event() for _ in range(depth)]
         self.i = 0
 
     def step(self, settings):
-        k = self.i & 1
-        if self.i >= 2:
-            self.s_render.wait_event(self.ev_comm[k])        # frame i-2's gather has read local[k]
-        self.scene.render_device(settings, self.local[k].data_ptr(), stream=self.s_render.cuda_stream)
-        self.ev_render[k].record(self.s_render)
+        k = self.i % self.depth
+        sr = self.s_render[k]
+        if self.i >= self.depth:
+            sr.wait_event(self.ev_comm[k])                   # frame i-depth's gather has read local[k]
+        self.scene.render_device(settings, self.local[k].data_ptr(), stream=sr.cuda_stream)
+        self.ev_render[k].record(sr)
         with torch.cuda.stream(self.s_comm):
             self.s_comm.wait_event(self.ev_render[k])
             if self.native is not None:

@@ -305,6 +305,34 @@ def test_tile_sharding_assembles_to_full_frame(main_pair, H):
         assert np.array_equal(tiles.assemble_numpy(gathered.cpu().numpy(), W, Hh, world), full)
 
 
+def test_frames_in_flight_on_different_streams(main_pair, H):
+    """Frames rendered on different streams overlap on the GPU (the scene keeps one set of work buffers per stream):
+    six frames -- three different settings, twice -- round-robin over three streams, none waited for, all
+    identical to the same frames rendered one at a time; stats report the frame enqueued last; a ninth stream is
+    refused loudly."""
+    import torch
+    g, _ = main_pair
+    W, Hh = 480, 270
+    cases = [dict(spp=8, seed=3), dict(spp=5, seed=4, max_bounce=1), dict(spp=16, seed=5)]
+    want = [g.render(W, Hh, want=("rgb",), **c)["rgb"] for c in cases]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [torch.zeros((Hh, W, 3), dtype=torch.uint8, device="cuda:0") for _ in range(6)]
+    torch.cuda.synchronize()
+    for i in range(6):
+        st = H.make_settings(W, Hh, **cases[i % 3])
+        g.render_device(st, outs[i].data_ptr(), stream=streams[(i + i // 3) % 3].cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(6):
+        assert np.array_equal(outs[i].cpu().numpy(), want[i % 3]), i
+    assert g.stats()["paths"] == W * Hh * cases[2]["spp"]
+    more = [torch.cuda.Stream() for _ in range(8)]
+    st = H.make_settings(W, Hh, spp=1)
+    with pytest.raises(Exception, match="streams"):
+        for s_ in more:
+            g.render_device(st, outs[0].data_ptr(), stream=s_.cuda_stream)
+    torch.cuda.synchronize()
+
+
 def test_native_rccl_gather_single_rank(main_pair, H):
     """rrt_comm_* / rrt_gather_tiles (the gather a host without Python calls): what one GPU can check -- RCCL is
     found and initialised inside librrt.so, a world of one gathers its own tiles (all-gather and gather-to-root),

@@ -1,0 +1,44 @@
+"""Frames in flight: the same frame rendered back to back on one stream against round-robin over 2, 3, 4 streams (the
+scene keeps one set of work buffers per stream).   python tools/two_stream.py [world] [spp] [frames] [cfg]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from rustraytracer_amd import host as H, scenes, distributed as D  # noqa: E402
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 40
+dev = torch.device("cuda", 0)
+cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
+bufs, streams = [], []
+w = getattr(scenes, cfg + "_scene")(H.World(device=0), H.loaders)
+w.commit()
+w.set_timing(0)
+for i in range(4):
+    if world > 1:
+        bufs.append(D.alloc_tile_buffers(1920, 1080, world, dev)[0])
+    else:
+        bufs.append(torch.empty(1080 * 1920 * 3, dtype=torch.uint8, device=dev))
+    streams.append(torch.cuda.Stream(device=dev))
+st = H.make_settings(1920, 1080, spp=spp, tile_rank=2 % world, tile_world=world)
+
+
+def run(n_streams):
+    for f in range(4):
+        w.render_device(st, bufs[f % n_streams].data_ptr(), stream=streams[f % n_streams].cuda_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(frames):
+        w.render_device(st, bufs[f % n_streams].data_ptr(), stream=streams[f % n_streams].cuda_stream)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / frames * 1e3
+
+
+for rep in range(2):
+    t = [run(n) for n in (1, 2, 3, 4)]
+    print("world %d spp %d %s: ms/frame with 1..4 frames in flight: %s" % (world, spp, cfg, " ".join("%.3f" % x for x in t)))
+for b in bufs[1:]:
+    assert torch.equal(bufs[0], b)
