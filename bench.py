@@ -278,8 +278,9 @@ def main():
     # a host without Python) instead of torch.distributed's; torch's group still carries the id and the barriers
     native = D.NativeComm(rank, world, dev) if world > 1 and os.environ.get("RRT_BENCH_GATHER", "torch") == "native" else None
     pipe = D.TilePipeline(scene, w, h, world, dev, frame, native=native, depth=depth) if world > 1 else None
-    scene.set_timing(0)          # no hipEvents between the launches of the timed frames (the sequential pass for the
-                                 # roofline turns them on)
+    # no hipEvents between the launches of the timed frames (the sequential pass for the roofline turns them on; with
+    # --in-flight 1 the timed pass is that sequential pass)
+    scene.set_timing(2 if world == 1 and depth == 1 else 0)
 
     def sync():
         if world > 1:

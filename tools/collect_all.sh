@@ -16,7 +16,7 @@ T=$TAG$SFX
 mkdir -p $OUT
 timeout -k 10 500 python3 bench.py $ARGS > $OUT/${T}_bench.json
 echo bench-done
-( cd /tmp && export TMPDIR=/tmp && timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T}_trace -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --once $ARGS > $OUT/${T}_trace.log 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${T}_trace -- python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --once --in-flight 1 $ARGS > $OUT/${T}_trace.log 2>&1 )
 echo trace-done
 bash tools/collect_pmc.sh $T $ARGS
 bash tools/collect_sq.sh $T $ARGS

@@ -10,6 +10,6 @@ REPO=$PWD
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 150 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $REPO/bench.py --steps 2 --warmup 1 --once --no-cpu-baseline "$@" > $OUT/$C.log 2>&1
+  timeout -s KILL 150 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -- python3 $REPO/bench.py --steps 2 --warmup 1 --once --in-flight 1 --no-cpu-baseline "$@" > $OUT/$C.log 2>&1
 done
 echo pmc-done
