@@ -1682,6 +1682,69 @@ __global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr, uint8_t
     }
 }
 
+// k_accumulate for batches packed with at least 16 samples a wave (pack_log2 >= 4, so ns is a multiple of 16): a QUAD
+// of lanes per pixel.  In a trip of 16 samples lane j of the quad reads samples 4j .. 4j + 3 -- its four tags are one
+// 16-byte load, the quad's 64 bytes and (for 16-sample groups) the wave's kilobyte are contiguous -- and the running
+// sum goes round the quad in sample order: lane 0 adds its four, hands the sum to lane 1 (a DPP quad broadcast, no
+// LDS), and so on; the order of the additions is that of the one-lane loop, so is every bit of the result.  Four times
+// the threads of the one-lane kernel, which is what a rank's thin frame needs (one wave per SIMD there otherwise).
+RRT_DEV double quad_bcast(double v, int j) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int l2, h2;
+    switch (j) {     // dpp_ctrl = quad_perm [j, j, j, j]
+    case 0: l2 = __builtin_amdgcn_update_dpp(lo, lo, 0x00, 0xf, 0xf, false); h2 = __builtin_amdgcn_update_dpp(hi, hi, 0x00, 0xf, 0xf, false); break;
+    case 1: l2 = __builtin_amdgcn_update_dpp(lo, lo, 0x55, 0xf, 0xf, false); h2 = __builtin_amdgcn_update_dpp(hi, hi, 0x55, 0xf, 0xf, false); break;
+    case 2: l2 = __builtin_amdgcn_update_dpp(lo, lo, 0xaa, 0xf, 0xf, false); h2 = __builtin_amdgcn_update_dpp(hi, hi, 0xaa, 0xf, 0xf, false); break;
+    default: l2 = __builtin_amdgcn_update_dpp(lo, lo, 0xff, 0xf, 0xf, false); h2 = __builtin_amdgcn_update_dpp(hi, hi, 0xff, 0xf, 0xf, false); break;
+    }
+    return __hiloint2double(h2, l2);
+}
+
+template <bool FINAL>
+__global__ __launch_bounds__(256) void k_accumulate_quad(DWork wk, DFrame fr, uint8_t* d_rgb8, double* d_color) {
+    __shared__ double by255[256];
+    by255[threadIdx.x] = (double)threadIdx.x / 255.0;          // cubemap.rs:70-74, one IEEE division per thread
+    __syncthreads();
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;      // grid = npx_local / 64 exactly
+    const uint32_t lp = gid >> 2, sub = gid & 3u;
+    const uint32_t N = fr.npx_local;
+    const uint32_t pp = (lp & ~255u) | tile_unswz(lp & 255u);
+    V3 acc = mk(0., 0., 0.);
+    if (fr.s0 != 0u) acc = mk(wk.accum[lp], wk.accum[lp + N], wk.accum[lp + 2 * (size_t)N]);
+    for (uint32_t s0 = 0; s0 < fr.ns; s0 += 16u) {
+        const uint32_t p0 = path_of(fr, s0, pp) + 4u * sub;    // samples s0 .. s0 + 15 of a pixel: consecutive paths
+        const uint4 tg = *(const uint4*)(wk.samp32 + p0);
+        const uint32_t tag[4] = {tg.x, tg.y, tg.z, tg.w};
+        V3 v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const size_t p = 3 * (size_t)(p0 + j);
+            v[j] = mk(0., 0., 0.);
+            if (!(tag[j] & kSampTexel)) v[j] = mk(wk.samp[p], wk.samp[p + 1], wk.samp[p + 2]);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const uint32_t t = tag[j];
+            if (t & kSampTexel) v[j] = mk(by255[t & 255u], by255[(t >> 8) & 255u], by255[(t >> 16) & 255u]);
+        }
+        const bool first = fr.s0 + s0 == 0u;                   // the frame's first sample starts the sum (no 0 + v)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            V3 a = acc;
+            a = (first && q == 0) ? v[0] : a + v[0];
+            a = a + v[1]; a = a + v[2]; a = a + v[3];
+            // every lane computed "the quad's sum so far + its own four"; lane q's is the one that is in order
+            acc = mk(quad_bcast(a.x, q), quad_bcast(a.y, q), quad_bcast(a.z, q));
+        }
+    }
+    if (sub != 0u) return;
+    if (FINAL) {
+        resolve_pixel(fr, lp, acc, d_rgb8, d_color);
+    } else {
+        wk.accum[lp] = acc.x; wk.accum[lp + N] = acc.y; wk.accum[lp + 2 * (size_t)N] = acc.z;
+    }
+}
+
 // [world][slots][8][32][3] -> row-major [H][W][3]
 __global__ __launch_bounds__(256) void k_assemble(const uint8_t* g, uint32_t w, uint32_t h, uint32_t world,
                                                   uint32_t slots, uint32_t tiles_x, uint32_t skew, uint8_t* out) {
@@ -1840,6 +1903,11 @@ void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t
     hipLaunchKernelGGL(k, dim3(bounce_grid()), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
 }
 void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream) {
+    if (fr.pack_log2 >= 4u) {
+        hipLaunchKernelGGL(final_batch ? k_accumulate_quad<true> : k_accumulate_quad<false>, dim3(fr.npx_local / 64), dim3(256), 0,
+                           (hipStream_t)stream, wk, fr, d_rgb8, d_color);
+        return;
+    }
     hipLaunchKernelGGL(final_batch ? k_accumulate<true> : k_accumulate<false>, dim3(fr.npx_local / 256), dim3(256), 0,
                        (hipStream_t)stream, wk, fr, d_rgb8, d_color);
 }
