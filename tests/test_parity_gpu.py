@@ -445,6 +445,38 @@ def test_cfg4_diffuse_ufo_bit_exact(H, O, scenes):
     assert 10 * np.log10(1.0 / mse) > 30.0
 
 
+@pytest.mark.parametrize("spp", [8, 12, 32, 48, 64])
+def test_sample_packing_bit_exact(H, O, scenes, main_pair, spp):
+    """A wave of the primary kernel is 64/S pixels x S samples, S = the largest power of two dividing the batch's
+    sample count (8, 4, 32, 16, 64 here), with path numbers, sample tags and the accumulate pass laid out to match:
+    the image is the oracle's whatever S is -- the UFO scene (mirror bounces), the diffuse scene (bounce rays draw
+    from RNG streams keyed by the path's decoded pixel and sample), three ranks' tiles, uneven batches."""
+    import torch
+    g, c = main_pair
+    W, Hh = 200, 120           # ragged against 32x8 tiles
+    co = c.render(W, Hh, spp=spp, seed=11)
+    _same(g.render(W, Hh, spp=spp, seed=11), co)
+    gd = scenes.cfg4_scene(H.World(device=0), H.loaders)
+    cd = scenes.cfg4_scene(O.OracleScene(), O)
+    do = cd.render(W, Hh, spp=spp, seed=12, want=("color", "rgb"))
+    _same(gd.render(W, Hh, spp=spp, seed=12, want=("color", "rgb")), do, keys=("color", "rgb"))
+    if spp in (32, 48):
+        # batches of 16 + a remainder, and a batch size that defeats the packing
+        for bs in (16, 20, 7):
+            gb = gd.render(W, Hh, spp=spp, seed=12, batch_spp=bs, want=("color",))
+            assert np.array_equal(gb["color"], do["color"]), bs
+        world = 3
+        slots = H.tile_slots(W, Hh, world)
+        gathered = torch.zeros((world, slots, 8, 32, 3), dtype=torch.uint8, device="cuda:0")
+        for r in range(world):
+            st = H.make_settings(W, Hh, spp=spp, seed=11, tile_rank=r, tile_world=world)
+            g.render_device(st, gathered[r].data_ptr())
+        out = torch.zeros((Hh, W, 3), dtype=torch.uint8, device="cuda:0")
+        H.assemble_tiles(gathered.data_ptr(), W, Hh, world, out.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), co["rgb"])
+
+
 def test_cfg5_synthetic_mesh(H, O, scenes):
     """Height-field meshes: 80 000 triangles bit-exact on a full frame, then the 2 000 000-triangle
     config (kd-tree with ~10^6 nodes, descent array too big for LDS -> global path) on strided rows."""
