@@ -443,6 +443,13 @@ def test_cfg4_diffuse_ufo_bit_exact(H, O, scenes):
     b = g.render(240, 135, spp=256, seed=2, want=("color",))["color"]
     mse = float(np.mean((np.clip(a, 0, 1) - np.clip(b, 0, 1)) ** 2))
     assert 10 * np.log10(1.0 / mse) > 30.0
+    # BASELINE configs[3] at its full size (3840x2160, 256 spp: 32 batches of 8 samples): strided rows against the oracle
+    big = g.render(3840, 2160, spp=256, seed=0, want=("color", "rgb"))
+    assert big["stats"]["n_batches"] > 1 and big["stats"]["traversal_overflow"] == 0
+    rows = np.arange(11, 2160, 500)
+    cb = c.render(3840, 2160, spp=256, seed=0, y0=11, row_stride=500, want=("color", "rgb"))
+    for k in ("color", "rgb"):
+        assert np.array_equal(big[k][rows], cb[k][rows]), k
 
 
 @pytest.mark.parametrize("spp", [8, 12, 32, 48, 64])
@@ -496,6 +503,13 @@ def test_cfg5_synthetic_mesh(H, O, scenes):
         assert np.array_equal(big[k][rows], cb[k][rows]), k
     tri = big["ids"][..., 1]
     assert tri.max() < 2000000 and len(np.unique(tri[tri >= 0])) > 100000
+    # BASELINE configs[4] at its full sample count (64 spp: two batches of 32, a wave = 2 pixels x 32 samples)
+    full = g.render(1920, 1080, spp=64, seed=0, want=("color", "rgb"))
+    assert full["stats"]["traversal_overflow"] == 0
+    rows = np.arange(13, 1080, 200)
+    cf = c.render(1920, 1080, spp=64, seed=0, y0=13, row_stride=200, want=("color", "rgb"))
+    for k in ("color", "rgb"):
+        assert np.array_equal(full[k][rows], cf[k][rows]), k
 
 
 def test_scene_groups_bit_exact(H, O, scenes):
