@@ -128,17 +128,41 @@ impl Model {
     }
 }
 
-/// `Scene::new(models, position)` (src/geometry/scene.rs:12-47): a kd-tree over whole entities.
-/// Members are spheres and models (groups do not nest on the GPU path).
+/// `Scene::new(models, position)` (src/geometry/scene.rs:31-47): a kd-tree over whole entities.
+/// Members are spheres and models (groups do not nest on the GPU path).  `position` is kept as the
+/// reference keeps it (scene.rs:45: stored, never read by `collide`).
 #[derive(Clone, Debug)]
 pub struct Scene {
     pub members: Vec<Entity>,
+    pub position: Vec3,
 }
 
 impl Scene {
-    pub fn new(members: Vec<Entity>) -> Scene {
-        Scene { members }
+    pub fn new(members: Vec<Entity>, position: Vec3) -> Scene {
+        Scene { members, position }
     }
+}
+
+/// `entity_enum!(Name, Type1, Type2, ...)` (src/geometry/scene.rs:12-21).  The reference generates an enum
+/// with one variant per listed type and derives `Entity` for it (derive_entity/src/lib.rs:7-51: every method
+/// forwards to the variant).  The GPU path has one closed set, so the name becomes an alias of it and the
+/// listed types are only checked to be variants.
+#[macro_export]
+macro_rules! entity_enum {
+    ($name:ident, $($x:ident),+) => {
+        #[allow(dead_code)]
+        type $name = $crate::Entity;
+        $( const _: fn($crate::$x) -> $crate::Entity = $crate::Entity::$x; )+
+    };
+}
+
+/// `scene!(EnumType, position, Type1(obj1), Type2(obj2), ...)` (src/geometry/scene.rs:23-29), so that
+/// main.rs:57-59 reads as it does in the reference.
+#[macro_export]
+macro_rules! scene {
+    ($type_name:ident, $position:expr, $($x:ident($y:ident)),+) => {
+        $crate::Scene::new(vec![$($type_name::$x($y)),+], $position)
+    };
 }
 
 /// The closed entity set (`entity_enum!` in the reference, src/geometry/scene.rs:54-75).
@@ -157,11 +181,31 @@ pub struct DirectionalLight {
     pub intensity: f64,
 }
 
+/// `PointLight::new(position, color, brightness, radius)` (src/lighting.rs:52-68).  `render` never reaches
+/// it in the reference (World::light_sources holds DirectionalLights only); here it is pushed behind the
+/// directional light (`rrt_add_point_light`), with `World::shadow_mode` choosing `visible()` as written
+/// (0, lighting.rs:70-84) or the corrected occlusion test (1).
+#[derive(Clone, Copy, Debug)]
+pub struct PointLight {
+    pub position: Vec3,
+    pub color: Vec3,
+    pub brightness: f64,
+    pub radius: f64,
+}
+
+impl PointLight {
+    pub fn new(position: Vec3, color: Vec3, brightness: f64, radius: f64) -> PointLight {
+        PointLight { position, color, brightness, radius }
+    }
+}
+
 /// `World` (src/common.rs:10-15).
 #[derive(Clone, Debug)]
 pub struct World {
     pub entities: Vec<Entity>,
     pub light_sources: Vec<DirectionalLight>,
+    pub point_lights: Vec<PointLight>,
+    pub shadow_mode: i32,
     /// Folder of the six cubemap PNGs (`Material::new_sky_material`, src/material.rs:35-42).
     pub sky: String,
     pub ambient: f64,
@@ -206,6 +250,8 @@ impl RayTracer {
                 color: color_vec(230.0, 230.0, 230.0),
                 intensity: 2.0,
             }],
+            point_lights: Vec::new(),
+            shadow_mode: 0,
             sky: format!("./cubemaps/{}", skybox),
             ambient: 0.15,
         }
@@ -247,6 +293,10 @@ impl RayTracer {
             check(unsafe { sys::rrt_set_directional_light(h.0, l.direction.as_ptr(), l.color.as_ptr(), l.intensity) })?;
         }
         check(unsafe { sys::rrt_set_ambient(h.0, world.ambient) })?;
+        for l in &world.point_lights {
+            check(unsafe { sys::rrt_add_point_light(h.0, l.position.as_ptr(), l.color.as_ptr(), l.brightness, l.radius) })?;
+        }
+        check(unsafe { sys::rrt_set_shadow_mode(h.0, world.shadow_mode) })?;
         for e in &world.entities {
             Self::add_entity(h.0, e, false)?;
         }
