@@ -64,6 +64,15 @@ struct Scene {
     static Scene new_(Point3 position, std::vector<Member> models) { return Scene{std::move(models), position}; }
 };
 
+// lighting.rs:52-68.  The reference never pushes one (World::light_sources holds DirectionalLights, common.rs:13);
+// here it goes behind the directional light, see rrt_add_point_light / rrt_set_shadow_mode.
+struct PointLight {
+    Point3 position; Vector3 color; double brightness, radius;
+    static PointLight new_(Point3 position, Vector3 color, double brightness, double radius) {
+        return PointLight{position, color, brightness, radius};
+    }
+};
+
 // common.rs:10-15 + RayTracer::new_empty_world (tracer.rs:53-75)
 class World {
   public:
@@ -96,6 +105,19 @@ class World {
         const int id = rrt_add_group(h_, ids.data(), (int32_t)ids.size());
         check(id);
         return id;
+    }
+    // world.light_sources.push(Box::new(light)) for a PointLight; shadow_mode 0 = PointLight::visible as written
+    // (lighting.rs:70-84), 1 = the occlusion test it was meant to be
+    void push(const PointLight& l, int shadow_mode = 0) {
+        const double p[3] = {l.position.x, l.position.y, l.position.z}, c[3] = {l.color.x, l.color.y, l.color.z};
+        check(rrt_add_point_light(h_, p, c, l.brightness, l.radius));
+        check(rrt_set_shadow_mode(h_, shadow_mode));
+    }
+    // entity.translate(vec)                     common.rs:46 / model.rs:80-86 / kdtree.rs:35-42: as written the
+    // boxes of a model's tree stay where they were (refit = false); refit = true moves them too
+    void translate(int entity, Vector3 vec, bool refit = false) {
+        const double v[3] = {vec.x, vec.y, vec.z};
+        check(rrt_translate_entity(h_, entity, v, refit ? 1 : 0));
     }
     rrt_scene* raw() const { return h_; }
 
