@@ -103,7 +103,7 @@ struct TimedLaunch {
 
 struct WorkSet {
     hipStream_t stream = nullptr;
-    DevBuf w_q[2], w_qcount, w_rec, w_samp, w_samp32, w_accum, w_stats;
+    DevBuf w_q[2], w_qcount, w_rec, w_samp, w_samp32, w_accum, w_stats, w_cover;
     // timing and counters of the last frame rendered with this set
     std::vector<TimedLaunch> timed;
     size_t timed_used = 0;
@@ -135,6 +135,8 @@ struct rrt_scene {
     std::vector<rrt::DMaterial> mats;
     std::vector<rrt::DSphere> spheres;
     std::vector<std::unique_ptr<HostMesh>> meshes;
+    std::vector<rrt::DMesh> dmeshes;          // host copies of what commit uploaded (device pointers + cull constants)
+    std::vector<std::pair<int32_t, int32_t>> cover;   // meshes that carry a primary-ray coverage mask: (mesh, stream entries), slot = position
     std::vector<std::unique_ptr<HostGroup>> groups;
     std::vector<double> sphere_radius;   // Sphere::bounding_box needs r, the kernels only r^2
     std::vector<rrt::DEntity> ents;
@@ -188,6 +190,8 @@ int commit(rrt_scene* s) {
     for (int f = 0; f < 6; ++f)
         if (s->sky[f].w == 0) return fail(RRT_E_STATE, "sky face " + std::to_string(f) + " not set (rrt_set_sky_face)");
     std::vector<rrt::DMesh> dm(s->meshes.size());
+    s->cover.clear();
+    static const bool cover_on = [] { const char* e = getenv("RRT_COVER"); return !e || atoi(e) != 0; }();   // A/B knob
     for (size_t i = 0; i < s->meshes.size(); ++i) {
         HostMesh& m = *s->meshes[i];
         const rrt::KdTreeFlat& T = m.tree;
@@ -345,8 +349,13 @@ int commit(rrt_scene* s) {
         dm[i].normals = m.d_normals.as<double>();
         dm[i].material = m.material;
         dm[i].flags = m.stale_boxes ? rrt::kTreeStaleBoxes : 0;
+        if (cover_on && stream.size() >= (size_t)rrt::kCoverMinEntries && s->cover.size() < (size_t)rrt::kMaxCover) {
+            s->cover.emplace_back((int32_t)i, (int32_t)stream.size());
+            dm[i].flags |= (int32_t)s->cover.size() << rrt::kCoverShift;      // slot + 1
+        }
     }
     HIP_TRY(s->d_meshes.upload(dm.data(), dm.size() * sizeof(rrt::DMesh)));
+    s->dmeshes = dm;
     std::vector<rrt::DGroup> dg(s->groups.size());
     for (size_t i = 0; i < s->groups.size(); ++i) {
         HostGroup& g = *s->groups[i];
@@ -591,8 +600,12 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
     return RRT_OK;
 }
 
-int ensure_work(WorkSet* s, const FramePlan& pl, rrt::DWork* wk) {
+uint64_t cover_bytes(const rrt::DFrame& fr) { return (uint64_t)fr.n_cover * fr.cover_words * 4; }
+
+int ensure_work(WorkSet* s, FramePlan& pl, rrt::DWork* wk) {
     const uint64_t P = pl.cap;
+    if (pl.fr.n_cover) HIP_TRY(s->w_cover.ensure(cover_bytes(pl.fr)));
+    pl.fr.cover = pl.fr.n_cover ? s->w_cover.as<uint32_t>() : nullptr;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(s->w_q[i].ensure(P * rrt::kRecDoubles * 8));
         wk->q[i] = s->w_q[i].as<double>();
@@ -619,12 +632,13 @@ constexpr uint64_t kCarveAlign = 256;
 uint64_t carve_bytes(const FramePlan& pl) {
     const uint64_t P = pl.cap;
     const uint64_t parts[] = {8 * 8, 2 * (rrt::kMaxLevels + 1) * 4, P * rrt::kRecDoubles * 8, P * rrt::kRecDoubles * 8,
-                              P * rrt::kRecDoubles * 8 * pl.levels, P * 3 * 8, P * 4, (uint64_t)pl.fr.npx_local * 3 * 8};
+                              P * rrt::kRecDoubles * 8 * pl.levels, P * 3 * 8, P * 4, (uint64_t)pl.fr.npx_local * 3 * 8,
+                              cover_bytes(pl.fr)};
     uint64_t total = 0;
     for (uint64_t b : parts) total += (b + kCarveAlign - 1) / kCarveAlign * kCarveAlign;
     return total;
 }
-int carve_work(unsigned char* base, uint64_t bytes, const FramePlan& pl, rrt::DWork* wk) {
+int carve_work(unsigned char* base, uint64_t bytes, FramePlan& pl, rrt::DWork* wk) {
     if (carve_bytes(pl) > bytes)
         return fail(RRT_E_NOMEM, "frame needs " + std::to_string(carve_bytes(pl)) + " B of scratch, the block has " + std::to_string(bytes));
     const uint64_t P = pl.cap;
@@ -642,6 +656,7 @@ int carve_work(unsigned char* base, uint64_t bytes, const FramePlan& pl, rrt::DW
     wk->samp = (double*)take(P * 3 * 8);
     wk->samp32 = (uint32_t*)take(P * 4);
     wk->accum = (double*)take((uint64_t)pl.fr.npx_local * 3 * 8);
+    pl.fr.cover = pl.fr.n_cover ? (const uint32_t*)take(cover_bytes(pl.fr)) : nullptr;
     wk->cap = P;
     return RRT_OK;
 }
@@ -665,8 +680,24 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
                   void* d_color, void* stream_v) {
     if (!s) return fail(RRT_E_INVALID, "null scene");
     FramePlan pl;
+    // Primary-ray coverage masks (kMaxCover in rrt_device.h): one bit per pixel of the whole image per masked mesh,
+    // refilled every frame (they depend on the camera).  Off with the cull (cull_mode 0 is "every test as written")
+    // and for a lens the projection does not cover.
+    uint64_t mask_bytes = 0;
+    uint32_t n_cover = 0;
+    const auto count_masks = [&]() {      // needs the committed scene
+        n_cover = 0;
+        mask_bytes = 0;
+        if (cam && st && st->width && st->height && !s->dirty && s->cull_mode != 0 && !s->cover.empty() && cam->lens_z > 0.0 &&
+            cam->lens_w > 0.0 && cam->lens_h > 0.0 && std::isfinite(cam->lens_z + cam->lens_w + cam->lens_h + cam->eye[0] + cam->eye[1] + cam->eye[2])) {
+            n_cover = (uint32_t)s->cover.size();
+            mask_bytes = (uint64_t)n_cover * ((uint64_t)((st->width + 31) / 32) * st->height + 1) * 4 + kCarveAlign;
+            if (NOALLOC && mask_bytes > rrt::kScratchBytes / 8) { n_cover = 0; mask_bytes = 0; }     // a huge image: leave the scratch to the paths
+        }
+    };
+    if (NOALLOC) count_masks();           // (an uncommitted scene is refused below)
     // the scratch block minus the two small headers; accum (24 B per pixel) is part of it
-    int rc = NOALLOC ? plan_frame(s, cam, st, &pl, rrt::kScratchBytes - 16 * kCarveAlign, 3 * 8) : plan_frame(s, cam, st, &pl, s->work_budget);
+    int rc = NOALLOC ? plan_frame(s, cam, st, &pl, rrt::kScratchBytes - 16 * kCarveAlign - mask_bytes, 3 * 8) : plan_frame(s, cam, st, &pl, s->work_budget);
     if (rc) {
         if (NOALLOC && rc == RRT_E_NOMEM)
             g_err = "rrt_render_device_noalloc: frame too large for the " + std::to_string(rrt::kScratchBytes >> 20) +
@@ -675,6 +706,8 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     }
     if (st->tile_world > 1 && (d_ids || d_t || d_color))
         return fail(RRT_E_INVALID, "AOV / f64 colour outputs need tile_world == 1");
+    pl.fr.cover_stride = (st->width + 31) / 32;
+    pl.fr.cover_words = pl.fr.cover_stride * st->height + 1;
     rrt::DWork wk{};
     hipStream_t stream = (hipStream_t)stream_v;
     WorkSet* ws = &s->noalloc_set;
@@ -684,11 +717,14 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         unsigned char* base = nullptr;
         const int e = rrt::scratch_base(s->device, &base);
         if (e != 0 || !base) return fail(RRT_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString((hipError_t)e));
+        pl.fr.n_cover = n_cover;
         rc = carve_work(base, rrt::kScratchBytes, pl, &wk);
         if (rc) return rc;
     } else {
         rc = commit(s);
         if (rc) return rc;
+        count_masks();
+        pl.fr.n_cover = n_cover;
         rc = work_set_for(s, stream, &ws);
         if (rc) return rc;
         rc = ensure_work(ws, pl, &wk);
@@ -705,6 +741,11 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     if (timed) HIP_TRY(hipEventRecord(ws->ev_begin, stream));
     HIP_TRY(hipMemsetAsync(wk.stats, 0, 8 * 8, stream));
     rrt::DFrame fr = pl.fr;
+    if (fr.n_cover) {
+        HIP_TRY(hipMemsetAsync(const_cast<uint32_t*>(fr.cover), 0, cover_bytes(fr), stream));
+        for (uint32_t k = 0; k < fr.n_cover; ++k)
+            rrt::launch_cover(s->dmeshes[(size_t)s->cover[k].first], s->cover[k].second, fr, k, stream);
+    }
     for (uint32_t b = 0; b < pl.n_batches; ++b) {
         fr.s0 = b * pl.batch_spp;
         fr.ns = std::min(pl.batch_spp, st->spp - fr.s0);

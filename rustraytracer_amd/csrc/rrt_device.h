@@ -82,7 +82,7 @@ struct DMesh {
     const DBox32* grp;      // per group of kGroup consecutive stream entries: union of their cull boxes
                             // (tris and grp carry kStreamPad extra entries for the loops to run into)
     int32_t material;
-    int32_t flags;          // kTreeStaleBoxes
+    int32_t flags;          // kTreeStaleBoxes | (coverage-mask slot + 1) << kCoverShift (0 = the mesh has no mask)
     // constants of the conservative cull (host-computed, f64)
     double center[3];       // root box centre
     double radius;          // root box half diagonal
@@ -138,6 +138,16 @@ struct DGroup {
 // the reference's full AABB::collide (aabb.rs:50-100, negative -> position (0,0,0), kdtree.rs:221-222), not its
 // inside arm alone.
 constexpr int32_t kTreeStaleBoxes = 1;
+
+// Primary-ray coverage masks.  Primary rays share the eye, so "can a ray through pixel (x, y) be accepted by any
+// triangle of this mesh?" has a conservative per-frame answer: k_cover projects every triangle (dilated by the same
+// acceptance bound the conservative cull uses) onto the image and sets the pixels of its bounding rectangle; a
+// primary ray whose pixel is clear skips Entity::collide of that mesh -- root box, set-up, walk -- with the miss
+// the walk would have returned.  One bit per pixel, rows of DFrame::cover_stride words, one trailing word that says
+// "treat every pixel as set" (a triangle at or behind the eye plane); up to kMaxCover meshes of a scene carry one.
+constexpr int32_t kCoverShift = 8;
+constexpr int32_t kMaxCover = 4;
+constexpr int32_t kCoverMinEntries = 256;   // smaller meshes are not worth a mask (their walk is a handful of leaves)
 
 struct DScene {
     const DEntity* ents;
@@ -209,6 +219,9 @@ struct DFrame {
     uint32_t s0, ns;         // first sample / samples in this batch
     uint32_t tile_skew;      // tile_skew(tiles_x, tile_world): row ty of the tile grid is rotated by tile_skew * ty columns
     uint32_t pack_log2;      // a wave of the primary kernel = 64 >> pack_log2 pixels x (1 << pack_log2) samples of this batch
+    // coverage masks of this frame (see kMaxCover): n_cover masks of cover_words words each, or n_cover = 0
+    const uint32_t* cover;
+    uint32_t n_cover, cover_stride, cover_words;
 };
 
 // Tile t (t % tile_world = owner, t / tile_world = slot) is the tile in row ty = t / tiles_x of the image, column
@@ -234,6 +247,8 @@ inline uint32_t tile_skew(uint32_t tiles_x, uint32_t world) {
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream);
 void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream);
 void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream);
+// Fills coverage mask `slot` of fr (zeroed by the caller) from the mesh's triangle stream (n entries).
+void launch_cover(const DMesh& mesh, int32_t n_entries, const DFrame& fr, uint32_t slot, void* stream);
 void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream);
 void launch_trace_rays(const DScene& sc, const double* d_rays, int64_t n, int32_t* ent, int32_t* tri, double* t,
                        double* pos, double* nrm, unsigned long long* stats, void* stream);

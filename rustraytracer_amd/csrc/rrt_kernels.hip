@@ -650,7 +650,8 @@ constexpr NoLds kNoLds{};
 // read back with v_readlane, a VALU slot each), and the six sky faces are picked per lane with
 // select chains.  From LDS they arrive where they are used, as VGPR operands: indices in doubles.
 constexpr int32_t kCLightDir = 0, kCLightColor = 3, kCIntensity = 6, kCAmbient = 7, kCEye = 8, kCLensZ = 11,
-                  kCLensW = 12, kCLensH = 13, kCFaces = 14 /* 6 x {ptr, w, h}: 2 doubles each */, kCDoubles = 26;
+                  kCLensW = 12, kCLensH = 13, kCFaces = 14 /* 6 x {ptr, w, h}: 2 doubles each */,
+                  kCCover = 26 /* {ptr, n_cover, cover_stride, cover_words, -}: 3 doubles */, kCDoubles = 29;
 RRT_DEV V3 ld3l(const RRT_LDS double* p) { return V3{p[0], p[1], p[2]}; }
 
 // Per-lane read of a field of an LDS-staged struct (the record index differs per lane).
@@ -682,7 +683,8 @@ RRT_DEV T lds_uniform(const RRT_LDS uint32_t* p) {
 // `rec` != nullptr: entity e's LDS record (e is wave-uniform then); nullptr: read from global memory.
 template <int CULL, bool REC, bool ANY = false>
 RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LDS uint32_t* rec, int32_t e, DEntity ent,
-                            V3 o, V3 d, int32_t medium, Closest* best, unsigned long long* stats, double lim2 = 0.0) {
+                            V3 o, V3 d, int32_t medium, Closest* best, unsigned long long* stats, double lim2 = 0.0,
+                            uint32_t cov = ~0u) {
     if ((RRT_ABL & 4) && ent.kind == 0) return;
     if ((RRT_ABL & 2) && ent.kind != 0) return;
     if (ent.kind == 0) {
@@ -715,8 +717,17 @@ RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LD
             ltop = so < 0;
             if (so != 0) ln = lnodes + ((ltop ? -so : so) - 1);
         }
+        // primary rays: the frame's coverage mask of this mesh says no triangle can accept a ray through this pixel
+        // (cov is all ones for every other ray, and the test folds away)
+        bool masked = false;
+        if (CULL != 0 && !ANY) {
+            const int32_t cs = (M.flags >> kCoverShift) & 15;
+            masked = cs != 0 && ((cov >> (cs - 1)) & 1u) == 0u;
+            if (CULL == 1 && masked) return;
+        }
         LeafBest h;
         mesh_collide<CULL, ANY>(M, K, ln, ltop, o, d, &h, stats, lim2);
+        if (CULL == 2 && masked && h.entry >= 0) atomicAdd(&stats[2], 1ull);    // verify mode: the mask must have been right
         // same |pos - origin|^2 as the leaf-level metric (kdtree.rs:206 == tracer.rs:184)
         if (h.entry >= 0 && h.dist < best->dist) {
             best->dist = h.dist; best->t = h.t; best->ent = e; best->entry = h.entry;
@@ -729,7 +740,7 @@ RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LD
 // that member (its entity id), or ent = -1.
 template <int CULL, bool ANY = false, class LDS = NoLds>
 RRT_DEV void group_collide(const DScene& sc, LDS lds, const DGroup& G, const DNodeI* lnodes, V3 o, V3 d, int32_t medium,
-                           Closest* out, unsigned long long* stats, double lim2 = 0.0) {
+                           Closest* out, unsigned long long* stats, double lim2 = 0.0, uint32_t cov = ~0u) {
     out->dist = kF64Max; out->t = 0.0; out->ent = -1; out->entry = -1;
     const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
     V3 point;
@@ -762,14 +773,14 @@ RRT_DEV void group_collide(const DScene& sc, LDS lds, const DGroup& G, const DNo
                         const RRT_LDS uint32_t* rec = lds.ents + eu * kEntRec;
                         DEntity ent = lds_uniform<DEntity>(rec);
                         ent.kind &= ~kEntityMember;        // 0 sphere or 1 mesh (rrt_add_group admits nothing else)
-                        entity_collide<CULL, true, ANY>(sc, lnodes, rec, eu, ent, o, d, medium, &best, stats, lim2);
+                        entity_collide<CULL, true, ANY>(sc, lnodes, rec, eu, ent, o, d, medium, &best, stats, lim2, cov);
                         todo = false;
                     }
                 }
             } else {
                 DEntity ent = sc.ents[e];
                 ent.kind &= ~kEntityMember;
-                entity_collide<CULL, false, ANY>(sc, lnodes, nullptr, e, ent, o, d, medium, &best, stats, lim2);   // e differs per lane
+                entity_collide<CULL, false, ANY>(sc, lnodes, nullptr, e, ent, o, d, medium, &best, stats, lim2, cov);   // e differs per lane
             }
             if (ANY && best.dist < lim2) break;
         }
@@ -791,7 +802,7 @@ RRT_DEV void group_collide(const DScene& sc, LDS lds, const DGroup& G, const DNo
 // entities (kind 2); their members carry kEntityMember and are not in world.entities.
 template <int CULL, bool GROUPS, class LDS>
 RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, Closest* best,
-                         unsigned long long* stats) {
+                         unsigned long long* stats, uint32_t cov = ~0u) {
     const DNodeI* lnodes = lds.nodes;
     best->dist = kF64Max; best->t = 0.0; best->ent = -1; best->entry = -1;
     for (int32_t e = 0; e < sc.n_ents; ++e) {
@@ -810,12 +821,12 @@ RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, 
                 if constexpr (LDS::kSmall) G = lds_uniform<DGroup>(rec + 2);
                 else G = sc.groups[ent.index];
                 Closest h;
-                group_collide<CULL, false>(sc, lds, G, lnodes, o, d, medium, &h, stats);
+                group_collide<CULL, false>(sc, lds, G, lnodes, o, d, medium, &h, stats, 0.0, cov);
                 if (h.ent >= 0 && h.dist < best->dist) *best = h;
                 continue;
             }
         }
-        entity_collide<CULL, LDS::kSmall>(sc, lnodes, rec, e, ent, o, d, medium, best, stats);
+        entity_collide<CULL, LDS::kSmall>(sc, lnodes, rec, e, ent, o, d, medium, best, stats, 0.0, cov);
     }
 }
 
@@ -1211,6 +1222,30 @@ RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y
     return *x < fr.width && *y < fr.height;
 }
 
+// Coverage bits of the primary ray through pixel (x, y): bit k clear = no triangle of the mesh with mask slot k can
+// accept this ray (see kMaxCover in rrt_device.h), so its Entity::collide is answered "miss" without being run.
+template <class LDS>
+RRT_DEV uint32_t cover_bits(LDS lds, uint32_t x, uint32_t y) {
+    uint32_t cov = ~0u;
+    if constexpr (LDS::kStaged) {
+        const RRT_LDS uint32_t* cv = (const RRT_LDS uint32_t*)(lds.consts + kCCover);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv[2]);
+        if (n != 0u) {
+            const RRT_GLOBAL uint32_t* m = as_global(lds_field<const uint32_t*>(cv, 0));
+            const uint32_t stride = cv[3], words = cv[4];
+            const uint32_t at = y * stride + (x >> 5);
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)kMaxCover; ++k) {
+                if (k < n) {
+                    const uint32_t w = m[k * words + at], all = m[k * words + words - 1u];
+                    if ((((w >> (x & 31u)) | all) & 1u) == 0u) cov &= ~(1u << k);
+                }
+            }
+        }
+    }
+    return cov;
+}
+
 // One cast() (tracer.rs:177-211) of path `path` at depth `bounce`.
 // Appends the continuation rays of a wave's casts at depth `bounce` to the queue of depth bounce + 1 (all lanes of
 // the wave call this together).  Live rays fill the queue from its front, dead (mix 0.0) rays from its back: a
@@ -1245,7 +1280,7 @@ template <bool PRIMARY, int CULL, bool GROUPS, bool PL, class LDS>
 RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFrame& fr, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
                          uint32_t pixel, uint32_t sample, uint32_t tag_base, bool dead_sky = false,
-                         unsigned long long* tacc = nullptr, NextRay* next = nullptr) {
+                         unsigned long long* tacc = nullptr, NextRay* next = nullptr, uint32_t cov = ~0u) {
     const uint64_t P = wk.cap;
     const uint32_t tag_off = path * 4u;
     (void)tag_base;
@@ -1257,7 +1292,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
         Closest c;
         CNT(0);
         const unsigned long long tc0 = TSTAMP();
-        closest_hit<CULL, GROUPS>(sc, lds, o, d, medium, &c, wk.stats);
+        closest_hit<CULL, GROUPS>(sc, lds, o, d, medium, &c, wk.stats, cov);
         if (RRT_PROBE == 2 && tacc) *tacc += TSTAMP() - tc0;
         (void)tc0;
         Hit h;
@@ -1442,6 +1477,10 @@ RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned 
                 f[4 * i] = (uint32_t)p; f[4 * i + 1] = (uint32_t)(p >> 32);
                 f[4 * i + 2] = sc.sky_w[i]; f[4 * i + 3] = sc.sky_h[i];
             }
+            RRT_LDS uint32_t* cv = (RRT_LDS uint32_t*)(c + kCCover);
+            const uint64_t cp = (uint64_t)fr.cover;
+            cv[0] = (uint32_t)cp; cv[1] = (uint32_t)(cp >> 32);
+            cv[2] = fr.cover ? fr.n_cover : 0u; cv[3] = fr.cover_stride; cv[4] = fr.cover_words; cv[5] = 0u;
         }
         st.consts = c;
     }
@@ -1497,8 +1536,13 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         const bool active = tile < fr.tiles_x * fr.tiles_y && x < fr.width && y < fr.height;
         const uint32_t sample = fr.s0 + s_local;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
-        if (active) primary_ray(fr, lds, x, y, sample, &o, &d);
-        process_ray<true, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample, tag_base);
+        uint32_t cov = ~0u;
+        if (active) {
+            if (CULL != 0) cov = cover_bits(lds, x, y);       // requested before the ray is generated
+            primary_ray(fr, lds, x, y, sample, &o, &d);
+        }
+        process_ray<true, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample, tag_base,
+                                            false, nullptr, nullptr, cov);
     }
 }
 
@@ -1745,6 +1789,79 @@ __global__ __launch_bounds__(256) void k_accumulate_quad(DWork wk, DFrame fr, ui
     }
 }
 
+// Coverage mask of one mesh for one frame (see kMaxCover in rrt_device.h).  Thread = stream entry (a triangle; the
+// entries a triangle is duplicated into just set the same bits again).
+//   Claim used: if Triangle::collide (triangle.rs:25-58, f64) ACCEPTS a ray (o, d), the line through o along d passes
+//   within `delta` of the triangle at a parameter >= -dt -- the bound behind the conservative cull (make_cull_ray:
+//   delta is its `pad` without the f32 term, dt its -tmin), doubled here.  Primary rays start at the eye, so with the
+//   triangle's dilated hull entirely in front of the eye plane (z - delta > 2 dt: otherwise the mask's "all" word is
+//   set) that point of the line projects through the eye onto the ray's own lens point, i.e. into the ray's pixel
+//   [x, x+1) x [y, y+1) (tracer.rs:126-131 + jitter in [0,1)).  A perspective image of a triangle in front of the eye
+//   is the triangle of its projected corners; dilating by delta moves a projection u = x/z by at most
+//   delta (1 + |u|) / (z - delta).  The mask takes the bounding rectangle of all that plus one whole pixel each side
+//   (thirteen orders of magnitude above the rounding of the reference's own ray generation).
+// Non-finite intermediate values set the "all" word as well.  Verified in cull mode 2 (a masked ray that the walk
+// nevertheless answers counts as a cull violation).
+struct CoverParams {
+    double eye[3], lens_z, lens_w, lens_h;
+    double delta, z_near;
+    uint32_t width, height, stride, words;
+};
+__global__ __launch_bounds__(256) void k_cover(const DTri* tris, int32_t n, CoverParams p, uint32_t* mask) {
+    const int32_t j = (int32_t)(blockIdx.x * 256u + threadIdx.x);
+    bool big = false;
+    int32_t x0 = 0, x1 = -1, y0 = 0, y1 = -1;
+    if (j < n) {
+        const RRT_GLOBAL DTri* T = as_global(tris) + j;
+        const V3 eye = mk(p.eye[0], p.eye[1], p.eye[2]);
+        const V3 v0 = ld3g(T->v0) - eye, v1 = (ld3g(T->v0) + ld3g(T->e1)) - eye, v2 = (ld3g(T->v0) + ld3g(T->e2)) - eye;
+        const double zmin = fmin(v0.z, fmin(v1.z, v2.z)) - p.delta;
+        bool all = !(zmin > p.z_near);                      // also catches NaN
+        if (!all) {
+            const double u0 = v0.x / v0.z, u1 = v1.x / v1.z, u2 = v2.x / v2.z;
+            const double w0 = v0.y / v0.z, w1 = v1.y / v1.z, w2 = v2.y / v2.z;
+            const double ulo = fmin(u0, fmin(u1, u2)), uhi = fmax(u0, fmax(u1, u2));
+            const double wlo = fmin(w0, fmin(w1, w2)), whi = fmax(w0, fmax(w1, w2));
+            const double g = 2.0 * p.delta / zmin;
+            const double mu = g * (1.0 + fmax(fabs(ulo), fabs(uhi))), mw = g * (1.0 + fmax(fabs(wlo), fabs(whi)));
+            // lens point of direction (u, w, 1): fx = (u lens_z + lens_w / 2) / lens_w, pixel coordinate fx * width
+            const double sx = p.lens_z / p.lens_w * (double)p.width, sy = p.lens_z / p.lens_h * (double)p.height;
+            const double pxlo = (ulo - mu) * sx + 0.5 * (double)p.width - 1.0, pxhi = (uhi + mu) * sx + 0.5 * (double)p.width + 1.0;
+            const double pylo = (wlo - mw) * sy + 0.5 * (double)p.height - 1.0, pyhi = (whi + mw) * sy + 0.5 * (double)p.height + 1.0;
+            if (!(fabs(pxlo) <= 1e300 && fabs(pxhi) <= 1e300 && fabs(pylo) <= 1e300 && fabs(pyhi) <= 1e300)) {
+                all = true;
+            } else if (pxhi >= 0.0 && pyhi >= 0.0 && pxlo < (double)p.width && pylo < (double)p.height) {
+                x0 = (int32_t)floor(fmax(pxlo, 0.0)); x1 = (int32_t)floor(fmin(pxhi, (double)p.width - 1.0));
+                y0 = (int32_t)floor(fmax(pylo, 0.0)); y1 = (int32_t)floor(fmin(pyhi, (double)p.height - 1.0));
+            }
+        }
+        if (all) atomicOr(&mask[p.words - 1u], 1u);
+        big = x1 >= x0 && y1 >= y0 && (int64_t)((x1 >> 5) - (x0 >> 5) + 1) * (y1 - y0 + 1) > 16;
+        if (!big) {
+            for (int32_t y = y0; y <= y1; ++y)
+                for (int32_t wx = x0 >> 5; wx <= (x1 >> 5); ++wx) {
+                    const uint32_t lo = wx == (x0 >> 5) ? (uint32_t)x0 & 31u : 0u, hi = wx == (x1 >> 5) ? (uint32_t)x1 & 31u : 31u;
+                    const uint32_t bits = (0xffffffffu >> (31u - hi)) & (0xffffffffu << lo);
+                    uint32_t* w = mask + (size_t)y * p.stride + wx;
+                    if ((*w & bits) != bits) atomicOr(w, bits);
+                }
+        }
+    }
+    // rectangles of more than 16 words: the wave fills them together, one after the other
+    for (unsigned long long todo = __ballot(big); todo != 0ull; todo &= todo - 1ull) {
+        const int src = __ffsll((long long)todo) - 1;
+        const int32_t bx0 = __shfl(x0, src, 64), bx1 = __shfl(x1, src, 64), by0 = __shfl(y0, src, 64), by1 = __shfl(y1, src, 64);
+        const int32_t wx0 = bx0 >> 5, nwx = (bx1 >> 5) - wx0 + 1, total = nwx * (by1 - by0 + 1);
+        for (int32_t i = (int32_t)(threadIdx.x & 63u); i < total; i += 64) {
+            const int32_t y = by0 + i / nwx, wx = wx0 + i % nwx;
+            const uint32_t lo = wx == (bx0 >> 5) ? (uint32_t)bx0 & 31u : 0u, hi = wx == (bx1 >> 5) ? (uint32_t)bx1 & 31u : 31u;
+            const uint32_t bits = (0xffffffffu >> (31u - hi)) & (0xffffffffu << lo);
+            uint32_t* w = mask + (size_t)y * p.stride + wx;
+            if ((*w & bits) != bits) atomicOr(w, bits);
+        }
+    }
+}
+
 // [world][slots][8][32][3] -> row-major [H][W][3]
 __global__ __launch_bounds__(256) void k_assemble(const uint8_t* g, uint32_t w, uint32_t h, uint32_t world,
                                                   uint32_t slots, uint32_t tiles_x, uint32_t skew, uint8_t* out) {
@@ -1910,6 +2027,25 @@ void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint
     }
     hipLaunchKernelGGL(final_batch ? k_accumulate<true> : k_accumulate<false>, dim3(fr.npx_local / 256), dim3(256), 0,
                        (hipStream_t)stream, wk, fr, d_rgb8, d_color);
+}
+void launch_cover(const DMesh& mesh, int32_t n_entries, const DFrame& fr, uint32_t slot, void* stream) {
+    if (n_entries <= 0) return;
+    CoverParams p{};
+    double o1 = 0.0, omax = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        p.eye[a] = fr.cam.eye[a];
+        o1 += fabs(fr.cam.eye[a] - mesh.center[a]);
+        omax = fmax(omax, fabs(fr.cam.eye[a]));
+    }
+    p.lens_z = fr.cam.lens_z; p.lens_w = fr.cam.lens_w; p.lens_h = fr.cam.lens_h;
+    // make_cull_ray's bounds for a ray from the eye (|d|_1 <= sqrt 3), doubled; + the rounding of the projection itself
+    const double S = mesh.edge_max, R = o1 + mesh.radius;
+    p.delta = 2.0 * (2.5e-7 * S * S * 1.7320508075688774 * (R + S)) * 1.000001 + 1e-9 * (omax + mesh.abs_max) + 1e-300;
+    const double dt = 2.0 * (8e-8 * S * S * (R + S)) * 1.000001;
+    p.z_near = 2.0 * dt + 1e-9 * (omax + mesh.abs_max) + 1e-300;
+    p.width = fr.width; p.height = fr.height; p.stride = fr.cover_stride; p.words = fr.cover_words;
+    hipLaunchKernelGGL(k_cover, dim3(((uint32_t)n_entries + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, mesh.tris, n_entries, p,
+                       const_cast<uint32_t*>(fr.cover) + (size_t)slot * fr.cover_words);
 }
 void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream) {
     const uint32_t tiles_x = (w + RRT_TILE_W - 1) / RRT_TILE_W, tiles_y = (h + RRT_TILE_H - 1) / RRT_TILE_H;

@@ -6,7 +6,8 @@ import subprocess
 import sys
 import tempfile
 
-obj = open("rustraytracer_amd/csrc/rrt_kernels.o", "rb").read()
+import os
+obj = open(os.environ.get("OBJ", "rustraytracer_amd/csrc/rrt_kernels.o"), "rb").read()   # OBJ=/tmp/rrt_kernels_<variant>.o
 magic = b"__CLANG_OFFLOAD_BUNDLE__"
 at = obj.find(magic)
 if at < 0:
