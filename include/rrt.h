@@ -325,6 +325,20 @@ int rrt_cast_rays(rrt_scene* s, const double* rays, int64_t n, uint32_t max_boun
 
 int rrt_get_stats(const rrt_scene* s, rrt_stats* out);
 
+/* Inspection of a primary-ray coverage mask (no counterpart in the reference; the masks are an acceleration of
+ * the primary rays of RayTracer::render, src/tracer.rs:117-158, that never changes a result).  Per frame and per
+ * mesh of at least 256 stream entries (the first four such meshes of a scene) the renderer projects every triangle,
+ * dilated by the acceptance bound of Triangle::collide (src/geometry/triangle.rs:25-58) that the conservative cull
+ * uses too, through the eye onto the image and sets the pixels of its bounding rectangle; a primary ray through a
+ * clear pixel cannot be accepted by any triangle of that mesh, so the mesh's Entity::collide is answered "miss"
+ * without being run.  cull_mode 0 switches the masks off with the cull, cull_mode 2 verifies them (a masked ray the
+ * walk answers counts in rrt_stats.cull_violations).
+ * This call fills the mask of mesh entity `entity` for (cam, width, height) exactly as a render would and copies
+ * it to the host: `words` must hold ((width + 31) / 32) * height + 1 uint32 -- bit x & 31 of word
+ * y * ((width + 31) / 32) + x / 32 is pixel (x, y); the last word is non-zero when some triangle reaches the eye
+ * plane and every pixel counts as set.  RRT_E_STATE if that entity carries no mask. */
+int rrt_cover_mask(rrt_scene* s, const rrt_camera* cam, uint32_t width, uint32_t height, int entity, uint32_t* words);
+
 /* Flattened kd-tree of a mesh entity in pre-order, for inspection and tests.
  * boxes 6/node, split 1/node, axis 1/node (-1 = leaf), child 2/node (interior:
  * left,right; leaf: first,count into leaf_refs), ropes 6/node (-1 = none;

@@ -46,7 +46,7 @@ EXPORTS = [
     "rrt_scene_commit",
     "rrt_render", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_tile_skew", "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_gather_tiles", "rrt_assemble_tiles",
     "rrt_trace_rays", "rrt_cast_rays", "rrt_get_stats", "rrt_mesh_tree_sizes",
-    "rrt_mesh_tree_export", "rrt_selftest_math", "rrt_philox4x32_10",
+    "rrt_mesh_tree_export", "rrt_cover_mask", "rrt_selftest_math", "rrt_philox4x32_10",
     "rrt_host_load_model", "rrt_host_add_model", "rrt_host_load_model_ex", "rrt_host_add_model_ex", "rrt_host_load_png_rgb8",
     "rrt_host_save_png_rgb8", "rrt_host_load_cubemap", "rrt_host_free",
 ]
@@ -114,6 +114,7 @@ def _load():
     L.rrt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rrt_mesh_tree_sizes.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rrt_mesh_tree_export.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    L.rrt_cover_mask.argtypes = [vp, vp, C.c_uint32, C.c_uint32, i32, vp]
     L.rrt_selftest_math.argtypes = [i32, vp, vp, i64, vp]
     L.rrt_philox4x32_10.argtypes = [vp, vp, vp]
     L.rrt_philox4x32_10.restype = None

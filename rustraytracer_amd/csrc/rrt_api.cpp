@@ -1266,6 +1266,36 @@ static const rrt::KdTreeFlat* tree_of(const rrt_scene* s, int entity) {
     if (kind == 2) return &s->groups[(size_t)ent.index]->tree;
     return nullptr;
 }
+int rrt_cover_mask(rrt_scene* s, const rrt_camera* cam, uint32_t width, uint32_t height, int entity, uint32_t* words) {
+    if (!s || !cam || !words || width == 0 || height == 0) return fail(RRT_E_INVALID, "null argument or empty image");
+    if ((uint64_t)width * height > 0x7fffffffull) return fail(RRT_E_INVALID, "image too large");
+    if (entity < 0 || (size_t)entity >= s->ents.size() || (s->ents[(size_t)entity].kind & ~rrt::kEntityMember) != 1)
+        return fail(RRT_E_INVALID, "entity is not a mesh");
+    int rc = commit(s);
+    if (rc) return rc;
+    const int32_t mi = s->ents[(size_t)entity].index;
+    int slot = -1;
+    for (size_t k = 0; k < s->cover.size(); ++k)
+        if (s->cover[k].first == mi) slot = (int)k;
+    if (slot < 0 || !(cam->lens_z > 0.0 && cam->lens_w > 0.0 && cam->lens_h > 0.0))
+        return fail(RRT_E_STATE, "this mesh (or this lens) has no coverage mask");
+    rrt::DFrame fr{};
+    fr.cam = *cam;
+    fr.width = width;
+    fr.height = height;
+    fr.n_cover = 1;
+    fr.cover_stride = (width + 31) / 32;
+    fr.cover_words = fr.cover_stride * height + 1;
+    DevBuf buf;
+    HIP_TRY(buf.ensure((size_t)fr.cover_words * 4));
+    fr.cover = buf.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(buf.p, 0, (size_t)fr.cover_words * 4, nullptr));
+    rrt::launch_cover(s->dmeshes[(size_t)mi], s->cover[(size_t)slot].second, fr, 0, nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(words, buf.p, (size_t)fr.cover_words * 4, hipMemcpyDeviceToHost));
+    return RRT_OK;
+}
+
 int rrt_mesh_tree_sizes(const rrt_scene* s, int entity, int32_t* n_nodes, int32_t* n_leaf_refs) {
     if (!tree_of(s, entity)) return fail(RRT_E_INVALID, "entity is not a mesh or a group");
     const rrt::KdTreeFlat& T = *tree_of(s, entity);

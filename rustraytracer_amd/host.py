@@ -172,6 +172,15 @@ class World:
                                            _ptr(out["child"]), _ptr(out["ropes"]), _ptr(out["leaf_refs"])))
         return out
 
+    def cover_mask(self, ent, width, height, camera=None):
+        """The primary-ray coverage mask of mesh entity `ent` (rrt_cover_mask) as a bool image + the "all" flag."""
+        cam = camera or default_camera()
+        stride = (width + 31) // 32
+        words = np.zeros(stride * height + 1, np.uint32)
+        B.check(B.lib.rrt_cover_mask(self.h, C.byref(cam), width, height, ent, _ptr(words)))
+        bits = np.unpackbits(words[:-1].reshape(height, stride).view(np.uint8), axis=1, bitorder="little")[:, :width]
+        return bits.astype(bool), bool(words[-1])
+
     def trace_rays(self, rays):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
         n = rays.shape[0]
