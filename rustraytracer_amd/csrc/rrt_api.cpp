@@ -103,7 +103,7 @@ struct TimedLaunch {
 
 struct WorkSet {
     hipStream_t stream = nullptr;
-    DevBuf w_q[2], w_qcount, w_rec, w_samp, w_samp32, w_accum, w_stats, w_cover;
+    DevBuf w_q[2], w_qcount, w_rec, w_samp, w_samp32, w_accum, w_stats, w_cover, w_bins;
     // timing and counters of the last frame rendered with this set
     std::vector<TimedLaunch> timed;
     size_t timed_used = 0;
@@ -514,6 +514,7 @@ struct FramePlan {
     uint32_t n_batches = 0;
     uint64_t cap = 0;  // paths per batch
     uint64_t valid_px = 0;
+    bool want_bins = false;   // this frame fills DFrame::tile_bins
 };
 
 size_t bytes_per_path(uint32_t levels) {
@@ -601,11 +602,14 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
 }
 
 uint64_t cover_bytes(const rrt::DFrame& fr) { return (uint64_t)fr.n_cover * fr.cover_words * 4; }
+uint64_t bins_bytes(const rrt::DFrame& fr, bool want) { return want ? (uint64_t)fr.tiles_x * fr.tiles_y * 8 : 0; }
 
 int ensure_work(WorkSet* s, FramePlan& pl, rrt::DWork* wk) {
     const uint64_t P = pl.cap;
     if (pl.fr.n_cover) HIP_TRY(s->w_cover.ensure(cover_bytes(pl.fr)));
     pl.fr.cover = pl.fr.n_cover ? s->w_cover.as<uint32_t>() : nullptr;
+    if (pl.want_bins) HIP_TRY(s->w_bins.ensure(bins_bytes(pl.fr, true)));
+    pl.fr.tile_bins = pl.want_bins ? s->w_bins.as<uint64_t>() : nullptr;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(s->w_q[i].ensure(P * rrt::kRecDoubles * 8));
         wk->q[i] = s->w_q[i].as<double>();
@@ -633,7 +637,7 @@ uint64_t carve_bytes(const FramePlan& pl) {
     const uint64_t P = pl.cap;
     const uint64_t parts[] = {8 * 8, 2 * (rrt::kMaxLevels + 1) * 4, P * rrt::kRecDoubles * 8, P * rrt::kRecDoubles * 8,
                               P * rrt::kRecDoubles * 8 * pl.levels, P * 3 * 8, P * 4, (uint64_t)pl.fr.npx_local * 3 * 8,
-                              cover_bytes(pl.fr)};
+                              cover_bytes(pl.fr), bins_bytes(pl.fr, pl.want_bins)};
     uint64_t total = 0;
     for (uint64_t b : parts) total += (b + kCarveAlign - 1) / kCarveAlign * kCarveAlign;
     return total;
@@ -657,6 +661,7 @@ int carve_work(unsigned char* base, uint64_t bytes, FramePlan& pl, rrt::DWork* w
     wk->samp32 = (uint32_t*)take(P * 4);
     wk->accum = (double*)take((uint64_t)pl.fr.npx_local * 3 * 8);
     pl.fr.cover = pl.fr.n_cover ? (const uint32_t*)take(cover_bytes(pl.fr)) : nullptr;
+    pl.fr.tile_bins = pl.want_bins ? (const uint64_t*)take(bins_bytes(pl.fr, true)) : nullptr;
     wk->cap = P;
     return RRT_OK;
 }
@@ -683,16 +688,23 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     // Primary-ray coverage masks (kMaxCover in rrt_device.h): one bit per pixel of the whole image per masked mesh,
     // refilled every frame (they depend on the camera).  Off with the cull (cull_mode 0 is "every test as written")
     // and for a lens the projection does not cover.
+    // Tile bins (DFrame::tile_bins) go with them: which entities of a small scene a tile's primary rays can meet.
     uint64_t mask_bytes = 0;
     uint32_t n_cover = 0;
+    bool want_bins = false;
     const auto count_masks = [&]() {      // needs the committed scene
         n_cover = 0;
         mask_bytes = 0;
-        if (cam && st && st->width && st->height && !s->dirty && s->cull_mode != 0 && !s->cover.empty() && cam->lens_z > 0.0 &&
+        want_bins = false;
+        static const bool bins_on = [] { const char* e = getenv("RRT_BINS"); return !e || atoi(e) != 0; }();   // A/B knob
+        if (cam && st && st->width && st->height && !s->dirty && s->cull_mode != 0 && cam->lens_z > 0.0 &&
             cam->lens_w > 0.0 && cam->lens_h > 0.0 && std::isfinite(cam->lens_z + cam->lens_w + cam->lens_h + cam->eye[0] + cam->eye[1] + cam->eye[2])) {
             n_cover = (uint32_t)s->cover.size();
             mask_bytes = (uint64_t)n_cover * ((uint64_t)((st->width + 31) / 32) * st->height + 1) * 4 + kCarveAlign;
             if (NOALLOC && mask_bytes > rrt::kScratchBytes / 8) { n_cover = 0; mask_bytes = 0; }     // a huge image: leave the scratch to the paths
+            // bins are worth their launch once the frame has some paths (a 640x480 frame at 1 spp is four launches long)
+            want_bins = bins_on && s->dscene.lds_ents != 0 && s->ents.size() >= 2 && (uint64_t)st->width * st->height * st->spp >= (1u << 20);
+            if (want_bins) mask_bytes += (uint64_t)((st->width + 31) / 32) * ((st->height + 7) / 8) * 8 + kCarveAlign;
         }
     };
     if (NOALLOC) count_masks();           // (an uncommitted scene is refused below)
@@ -718,6 +730,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         const int e = rrt::scratch_base(s->device, &base);
         if (e != 0 || !base) return fail(RRT_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString((hipError_t)e));
         pl.fr.n_cover = n_cover;
+        pl.want_bins = want_bins;
         rc = carve_work(base, rrt::kScratchBytes, pl, &wk);
         if (rc) return rc;
     } else {
@@ -725,6 +738,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         if (rc) return rc;
         count_masks();
         pl.fr.n_cover = n_cover;
+        pl.want_bins = want_bins;
         rc = work_set_for(s, stream, &ws);
         if (rc) return rc;
         rc = ensure_work(ws, pl, &wk);
@@ -746,6 +760,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         for (uint32_t k = 0; k < fr.n_cover; ++k)
             rrt::launch_cover(s->dmeshes[(size_t)s->cover[k].first], s->cover[k].second, fr, k, stream);
     }
+    if (fr.tile_bins) rrt::launch_bins(s->dscene, fr, stream);
     for (uint32_t b = 0; b < pl.n_batches; ++b) {
         fr.s0 = b * pl.batch_spp;
         fr.ns = std::min(pl.batch_spp, st->spp - fr.s0);

@@ -222,6 +222,10 @@ struct DFrame {
     // coverage masks of this frame (see kMaxCover): n_cover masks of cover_words words each, or n_cover = 0
     const uint32_t* cover;
     uint32_t n_cover, cover_stride, cover_words;
+    // Tile bins of this frame, or nullptr: one 64-bit word per 32x8-pixel tile of the image (row-major over the tile
+    // grid), bit e clear = no primary ray through that tile can be answered by entity e (a sphere whose projected
+    // bounds miss the tile, a mesh whose coverage mask is clear over it).  Scenes of at most 64 entities.
+    const uint64_t* tile_bins;
 };
 
 // Tile t (t % tile_world = owner, t / tile_world = slot) is the tile in row ty = t / tiles_x of the image, column
@@ -249,6 +253,8 @@ void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t
 void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream);
 // Fills coverage mask `slot` of fr (zeroed by the caller) from the mesh's triangle stream (n entries).
 void launch_cover(const DMesh& mesh, int32_t n_entries, const DFrame& fr, uint32_t slot, void* stream);
+// Fills fr.tile_bins from the scene's spheres and the frame's coverage masks (after launch_cover).
+void launch_bins(const DScene& sc, const DFrame& fr, void* stream);
 void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream);
 void launch_trace_rays(const DScene& sc, const double* d_rays, int64_t n, int32_t* ent, int32_t* tri, double* t,
                        double* pos, double* nrm, unsigned long long* stats, void* stream);

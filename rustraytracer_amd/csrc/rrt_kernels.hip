@@ -740,7 +740,7 @@ RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LD
 // that member (its entity id), or ent = -1.
 template <int CULL, bool ANY = false, class LDS = NoLds>
 RRT_DEV void group_collide(const DScene& sc, LDS lds, const DGroup& G, const DNodeI* lnodes, V3 o, V3 d, int32_t medium,
-                           Closest* out, unsigned long long* stats, double lim2 = 0.0, uint32_t cov = ~0u) {
+                           Closest* out, unsigned long long* stats, double lim2 = 0.0, uint32_t cov = ~0u, uint64_t ebits = ~0ull) {
     out->dist = kF64Max; out->t = 0.0; out->ent = -1; out->entry = -1;
     const V3 inv = mk(1. / d.x, 1. / d.y, 1. / d.z);
     V3 point;
@@ -770,11 +770,14 @@ RRT_DEV void group_collide(const DScene& sc, LDS lds, const DGroup& G, const DNo
                 for (bool todo = true; todo;) {
                     const int32_t eu = __builtin_amdgcn_readfirstlane(e);
                     if (e == eu) {
+                        todo = false;
+                        const bool binned = CULL != 0 && !ANY && eu < 64 && ((ebits >> eu) & 1ull) == 0ull;   // see closest_hit
+                        if (CULL == 1 && binned) continue;
                         const RRT_LDS uint32_t* rec = lds.ents + eu * kEntRec;
                         DEntity ent = lds_uniform<DEntity>(rec);
                         ent.kind &= ~kEntityMember;        // 0 sphere or 1 mesh (rrt_add_group admits nothing else)
                         entity_collide<CULL, true, ANY>(sc, lnodes, rec, eu, ent, o, d, medium, &best, stats, lim2, cov);
-                        todo = false;
+                        if (CULL == 2 && binned && best.ent == eu) atomicAdd(&stats[2], 1ull);
                     }
                 }
             } else {
@@ -802,10 +805,14 @@ RRT_DEV void group_collide(const DScene& sc, LDS lds, const DGroup& G, const DNo
 // entities (kind 2); their members carry kEntityMember and are not in world.entities.
 template <int CULL, bool GROUPS, class LDS>
 RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, Closest* best,
-                         unsigned long long* stats, uint32_t cov = ~0u) {
+                         unsigned long long* stats, uint32_t cov = ~0u, uint64_t ebits = ~0ull) {
     const DNodeI* lnodes = lds.nodes;
     best->dist = kF64Max; best->t = 0.0; best->ent = -1; best->entry = -1;
     for (int32_t e = 0; e < sc.n_ents; ++e) {
+        // primary rays: the tile's bin says this entity cannot answer any ray through the tile (wave-uniform: a
+        // scalar branch); all ones for every other ray
+        const bool binned = CULL != 0 && e < 64 && ((ebits >> e) & 1ull) == 0ull;
+        if (CULL == 1 && binned) continue;
         const RRT_LDS uint32_t* rec = nullptr;
         DEntity ent;
         if constexpr (LDS::kSmall) {
@@ -821,12 +828,13 @@ RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, 
                 if constexpr (LDS::kSmall) G = lds_uniform<DGroup>(rec + 2);
                 else G = sc.groups[ent.index];
                 Closest h;
-                group_collide<CULL, false>(sc, lds, G, lnodes, o, d, medium, &h, stats, 0.0, cov);
+                group_collide<CULL, false>(sc, lds, G, lnodes, o, d, medium, &h, stats, 0.0, cov, ebits);
                 if (h.ent >= 0 && h.dist < best->dist) *best = h;
                 continue;
             }
         }
         entity_collide<CULL, LDS::kSmall>(sc, lnodes, rec, e, ent, o, d, medium, best, stats, 0.0, cov);
+        if (CULL == 2 && binned && best->ent == e) atomicAdd(&stats[2], 1ull);    // verify mode: the bin must have been right
     }
 }
 
@@ -1280,7 +1288,7 @@ template <bool PRIMARY, int CULL, bool GROUPS, bool PL, class LDS>
 RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFrame& fr, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
                          uint32_t pixel, uint32_t sample, uint32_t tag_base, bool dead_sky = false,
-                         unsigned long long* tacc = nullptr, NextRay* next = nullptr, uint32_t cov = ~0u) {
+                         unsigned long long* tacc = nullptr, NextRay* next = nullptr, uint32_t cov = ~0u, uint64_t ebits = ~0ull) {
     const uint64_t P = wk.cap;
     const uint32_t tag_off = path * 4u;
     (void)tag_base;
@@ -1292,7 +1300,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
         Closest c;
         CNT(0);
         const unsigned long long tc0 = TSTAMP();
-        closest_hit<CULL, GROUPS>(sc, lds, o, d, medium, &c, wk.stats, cov);
+        closest_hit<CULL, GROUPS>(sc, lds, o, d, medium, &c, wk.stats, cov, ebits);
         if (RRT_PROBE == 2 && tacc) *tacc += TSTAMP() - tc0;
         (void)tc0;
         Hit h;
@@ -1537,12 +1545,16 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         const uint32_t sample = fr.s0 + s_local;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         uint32_t cov = ~0u;
+        // the tile's bin: a 64-bit scalar through the entity loop (parked in LDS and looked up per entity instead, to
+        // spare the two SGPRs, it measured slower: cfg2 primary kernel 1.00 against 0.96 ms)
+        uint64_t ebits = ~0ull;
+        if (CULL != 0 && fr.tile_bins && tile < fr.tiles_x * fr.tiles_y) ebits = fr.tile_bins[ty * fr.tiles_x + tx];   // scalar load
         if (active) {
             if (CULL != 0) cov = cover_bits(lds, x, y);       // requested before the ray is generated
             primary_ray(fr, lds, x, y, sample, &o, &d);
         }
         process_ray<true, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample, tag_base,
-                                            false, nullptr, nullptr, cov);
+                                            false, nullptr, nullptr, cov, ebits);
     }
 }
 
@@ -1862,6 +1874,58 @@ __global__ __launch_bounds__(256) void k_cover(const DTri* tris, int32_t n, Cove
     }
 }
 
+// Tile bins (DFrame::tile_bins).  Thread = tile.  Sphere::collide (sphere.rs:28-47) accepts a ray when tca >= 0 and
+// d2 = |l|^2 - tca^2 <= r^2; its rounding moves d2 by less than 1e-15 |l|^2, so an accepted ray's line passes within
+// r' = r + 1e-12 (|l|^2 / r + r) of the centre (three orders of magnitude of slack), at a point in front of the eye.
+// The rays (u, v, 1) that touch a sphere of radius r' about (cx, cy, cz), cz - r' > 0, have
+// u in (cx cz -+ r' sqrt(cx^2 + cz^2 - r'^2)) / (cz^2 - r'^2) (tangent planes through the eye and the y direction) and
+// v likewise; the bin takes that rectangle plus one pixel each side.  Anything doubtful sets the bit.
+struct BinParams {
+    double eye[3], lens_z, lens_w, lens_h, z_slack;
+    uint32_t width, height, tiles_x, tiles_y;
+};
+__global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint32_t* cover, uint32_t n_cover, uint32_t stride,
+                                              uint32_t words, uint64_t* bins) {
+    const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
+    if (tile >= p.tiles_x * p.tiles_y) return;
+    const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+    const double x0 = (double)(tx * RRT_TILE_W), x1 = fmin(x0 + (double)RRT_TILE_W, (double)p.width);
+    const double y0 = (double)(ty * RRT_TILE_H), y1 = fmin(y0 + (double)RRT_TILE_H, (double)p.height);
+    const double sx = p.lens_z / p.lens_w * (double)p.width, sy = p.lens_z / p.lens_h * (double)p.height;
+    uint64_t bits = ~0ull;
+    for (int32_t e = 0; e < sc.n_ents && e < 64; ++e) {
+        const DEntity ent = sc.ents[e];
+        const int32_t kind = ent.kind & ~kEntityMember;
+        bool may = true;
+        if (kind == 0) {
+            const DSphere S = sc.spheres[ent.index];
+            const double cx = S.c[0] - p.eye[0], cy = S.c[1] - p.eye[1], cz = S.c[2] - p.eye[2];
+            const double r = sqrt(S.r2), l2 = cx * cx + cy * cy + cz * cz;
+            const double rr = r + 1e-12 * (l2 / r + r) + p.z_slack;
+            if (r > 0.0 && cz - rr > p.z_slack && fabs(l2) <= 1e300) {
+                const double den = cz * cz - rr * rr;
+                const double su = rr * sqrt(fmax(cx * cx + den, 0.0)), sv = rr * sqrt(fmax(cy * cy + den, 0.0));
+                const double ulo = (cx * cz - su) / den, uhi = (cx * cz + su) / den;
+                const double vlo = (cy * cz - sv) / den, vhi = (cy * cz + sv) / den;
+                const double pxlo = ulo * sx + 0.5 * (double)p.width - 1.0, pxhi = uhi * sx + 0.5 * (double)p.width + 1.0;
+                const double pylo = vlo * sy + 0.5 * (double)p.height - 1.0, pyhi = vhi * sy + 0.5 * (double)p.height + 1.0;
+                // written so that a NaN anywhere keeps the bit
+                if (pxhi < x0 || pxlo >= x1 || pyhi < y0 || pylo >= y1) may = false;
+            }
+        } else if (kind == 1) {
+            const int32_t cs = (sc.meshes[ent.index].flags >> kCoverShift) & 15;
+            if (cs != 0 && (uint32_t)cs <= n_cover) {
+                const uint32_t* m = cover + (size_t)(cs - 1) * words;
+                uint32_t any = m[words - 1u];
+                for (uint32_t y = ty * RRT_TILE_H; y < (ty + 1u) * RRT_TILE_H && y < p.height; ++y) any |= m[y * stride + tx];
+                may = any != 0u;
+            }
+        }
+        if (!may) bits &= ~(1ull << e);
+    }
+    bins[tile] = bits;
+}
+
 // [world][slots][8][32][3] -> row-major [H][W][3]
 __global__ __launch_bounds__(256) void k_assemble(const uint8_t* g, uint32_t w, uint32_t h, uint32_t world,
                                                   uint32_t slots, uint32_t tiles_x, uint32_t skew, uint8_t* out) {
@@ -2046,6 +2110,21 @@ void launch_cover(const DMesh& mesh, int32_t n_entries, const DFrame& fr, uint32
     p.width = fr.width; p.height = fr.height; p.stride = fr.cover_stride; p.words = fr.cover_words;
     hipLaunchKernelGGL(k_cover, dim3(((uint32_t)n_entries + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, mesh.tris, n_entries, p,
                        const_cast<uint32_t*>(fr.cover) + (size_t)slot * fr.cover_words);
+}
+void launch_bins(const DScene& sc, const DFrame& fr, void* stream) {
+    static_assert(RRT_TILE_W == 32, "a tile is one mask word wide");
+    BinParams p{};
+    double omax = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        p.eye[a] = fr.cam.eye[a];
+        omax = fmax(omax, fabs(fr.cam.eye[a]));
+    }
+    p.lens_z = fr.cam.lens_z; p.lens_w = fr.cam.lens_w; p.lens_h = fr.cam.lens_h;
+    p.z_slack = 1e-9 * omax + 1e-300;
+    p.width = fr.width; p.height = fr.height; p.tiles_x = fr.tiles_x; p.tiles_y = fr.tiles_y;
+    const uint32_t n = fr.tiles_x * fr.tiles_y;
+    hipLaunchKernelGGL(k_bins, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, sc, p, fr.cover, fr.cover ? fr.n_cover : 0u,
+                       fr.cover_stride, fr.cover_words, const_cast<uint64_t*>(fr.tile_bins));
 }
 void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream) {
     const uint32_t tiles_x = (w + RRT_TILE_W - 1) / RRT_TILE_W, tiles_y = (h + RRT_TILE_H - 1) / RRT_TILE_H;
