@@ -334,10 +334,10 @@ int rrt_get_stats(const rrt_scene* s, rrt_stats* out);
  * without being run.  cull_mode 0 switches the masks off with the cull, cull_mode 2 verifies them (a masked ray the
  * walk answers counts in rrt_stats.cull_violations).
  * This call fills the mask of mesh entity `entity` for (cam, width, height) exactly as a render would and copies
- * it to the host: `words` must hold ((width + 31) / 32) * height + 1 uint32 -- bit x & 31 of word
- * y * ((width + 31) / 32) + x / 32 is pixel (x, y); the last word is non-zero when some triangle reaches the eye
- * plane and every pixel counts as set.  RRT_E_STATE if that entity carries no mask. */
-int rrt_cover_mask(rrt_scene* s, const rrt_camera* cam, uint32_t width, uint32_t height, int entity, uint32_t* words);
+ * it to the host: pixels[y * width + x] = 1 if pixel (x, y) is set (the mask keeps one flag per cell of 4 x 1 pixels,
+ * so set pixels come in aligned runs of four), *every = 1 when some triangle reaches the eye plane and every pixel
+ * counts as set whatever `pixels` says.  RRT_E_STATE if that entity carries no mask. */
+int rrt_cover_mask(rrt_scene* s, const rrt_camera* cam, uint32_t width, uint32_t height, int entity, uint8_t* pixels, int* every);
 
 /* Flattened kd-tree of a mesh entity in pre-order, for inspection and tests.
  * boxes 6/node, split 1/node, axis 1/node (-1 = leaf), child 2/node (interior:

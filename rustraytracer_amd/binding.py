@@ -114,7 +114,7 @@ def _load():
     L.rrt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rrt_mesh_tree_sizes.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.rrt_mesh_tree_export.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
-    L.rrt_cover_mask.argtypes = [vp, vp, C.c_uint32, C.c_uint32, i32, vp]
+    L.rrt_cover_mask.argtypes = [vp, vp, C.c_uint32, C.c_uint32, i32, vp, vp]
     L.rrt_selftest_math.argtypes = [i32, vp, vp, i64, vp]
     L.rrt_philox4x32_10.argtypes = [vp, vp, vp]
     L.rrt_philox4x32_10.restype = None

@@ -601,13 +601,14 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
     return RRT_OK;
 }
 
-uint64_t cover_bytes(const rrt::DFrame& fr) { return (uint64_t)fr.n_cover * fr.cover_words * 4; }
+uint64_t cover_stride(uint32_t width) { return ((uint64_t)(width + rrt::kCoverCell - 1) / rrt::kCoverCell + 7) / 8 * 8; }
+uint64_t cover_bytes(const rrt::DFrame& fr) { return (uint64_t)fr.n_cover * fr.cover_bytes; }
 uint64_t bins_bytes(const rrt::DFrame& fr, bool want) { return want ? (uint64_t)fr.tiles_x * fr.tiles_y * 8 : 0; }
 
 int ensure_work(WorkSet* s, FramePlan& pl, rrt::DWork* wk) {
     const uint64_t P = pl.cap;
     if (pl.fr.n_cover) HIP_TRY(s->w_cover.ensure(cover_bytes(pl.fr)));
-    pl.fr.cover = pl.fr.n_cover ? s->w_cover.as<uint32_t>() : nullptr;
+    pl.fr.cover = pl.fr.n_cover ? s->w_cover.as<uint8_t>() : nullptr;
     if (pl.want_bins) HIP_TRY(s->w_bins.ensure(bins_bytes(pl.fr, true)));
     pl.fr.tile_bins = pl.want_bins ? s->w_bins.as<uint64_t>() : nullptr;
     for (int i = 0; i < 2; ++i) {
@@ -660,7 +661,7 @@ int carve_work(unsigned char* base, uint64_t bytes, FramePlan& pl, rrt::DWork* w
     wk->samp = (double*)take(P * 3 * 8);
     wk->samp32 = (uint32_t*)take(P * 4);
     wk->accum = (double*)take((uint64_t)pl.fr.npx_local * 3 * 8);
-    pl.fr.cover = pl.fr.n_cover ? (const uint32_t*)take(cover_bytes(pl.fr)) : nullptr;
+    pl.fr.cover = pl.fr.n_cover ? (const uint8_t*)take(cover_bytes(pl.fr)) : nullptr;
     pl.fr.tile_bins = pl.want_bins ? (const uint64_t*)take(bins_bytes(pl.fr, true)) : nullptr;
     wk->cap = P;
     return RRT_OK;
@@ -700,7 +701,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         if (cam && st && st->width && st->height && !s->dirty && s->cull_mode != 0 && cam->lens_z > 0.0 &&
             cam->lens_w > 0.0 && cam->lens_h > 0.0 && std::isfinite(cam->lens_z + cam->lens_w + cam->lens_h + cam->eye[0] + cam->eye[1] + cam->eye[2])) {
             n_cover = (uint32_t)s->cover.size();
-            mask_bytes = (uint64_t)n_cover * ((uint64_t)((st->width + 31) / 32) * st->height + 1) * 4 + kCarveAlign;
+            mask_bytes = (uint64_t)n_cover * (cover_stride(st->width) * st->height + 8) + kCarveAlign;
             if (NOALLOC && mask_bytes > rrt::kScratchBytes / 8) { n_cover = 0; mask_bytes = 0; }     // a huge image: leave the scratch to the paths
             // bins are worth their launch once the frame has some paths (a 640x480 frame at 1 spp is four launches long)
             want_bins = bins_on && s->dscene.lds_ents != 0 && s->ents.size() >= 2 && (uint64_t)st->width * st->height * st->spp >= (1u << 20);
@@ -718,8 +719,8 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     }
     if (st->tile_world > 1 && (d_ids || d_t || d_color))
         return fail(RRT_E_INVALID, "AOV / f64 colour outputs need tile_world == 1");
-    pl.fr.cover_stride = (st->width + 31) / 32;
-    pl.fr.cover_words = pl.fr.cover_stride * st->height + 1;
+    pl.fr.cover_stride = (uint32_t)cover_stride(st->width);
+    pl.fr.cover_bytes = pl.fr.cover_stride * st->height + 8;
     rrt::DWork wk{};
     hipStream_t stream = (hipStream_t)stream_v;
     WorkSet* ws = &s->noalloc_set;
@@ -756,7 +757,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     HIP_TRY(hipMemsetAsync(wk.stats, 0, 8 * 8, stream));
     rrt::DFrame fr = pl.fr;
     if (fr.n_cover) {
-        HIP_TRY(hipMemsetAsync(const_cast<uint32_t*>(fr.cover), 0, cover_bytes(fr), stream));
+        HIP_TRY(hipMemsetAsync(const_cast<uint8_t*>(fr.cover), 0, cover_bytes(fr), stream));
         for (uint32_t k = 0; k < fr.n_cover; ++k)
             rrt::launch_cover(s->dmeshes[(size_t)s->cover[k].first], s->cover[k].second, fr, k, stream);
     }
@@ -1281,8 +1282,8 @@ static const rrt::KdTreeFlat* tree_of(const rrt_scene* s, int entity) {
     if (kind == 2) return &s->groups[(size_t)ent.index]->tree;
     return nullptr;
 }
-int rrt_cover_mask(rrt_scene* s, const rrt_camera* cam, uint32_t width, uint32_t height, int entity, uint32_t* words) {
-    if (!s || !cam || !words || width == 0 || height == 0) return fail(RRT_E_INVALID, "null argument or empty image");
+int rrt_cover_mask(rrt_scene* s, const rrt_camera* cam, uint32_t width, uint32_t height, int entity, uint8_t* pixels, int* every) {
+    if (!s || !cam || !pixels || !every || width == 0 || height == 0) return fail(RRT_E_INVALID, "null argument or empty image");
     if ((uint64_t)width * height > 0x7fffffffull) return fail(RRT_E_INVALID, "image too large");
     if (entity < 0 || (size_t)entity >= s->ents.size() || (s->ents[(size_t)entity].kind & ~rrt::kEntityMember) != 1)
         return fail(RRT_E_INVALID, "entity is not a mesh");
@@ -1299,15 +1300,19 @@ int rrt_cover_mask(rrt_scene* s, const rrt_camera* cam, uint32_t width, uint32_t
     fr.width = width;
     fr.height = height;
     fr.n_cover = 1;
-    fr.cover_stride = (width + 31) / 32;
-    fr.cover_words = fr.cover_stride * height + 1;
+    fr.cover_stride = (uint32_t)cover_stride(width);
+    fr.cover_bytes = fr.cover_stride * height + 8;
     DevBuf buf;
-    HIP_TRY(buf.ensure((size_t)fr.cover_words * 4));
-    fr.cover = buf.as<uint32_t>();
-    HIP_TRY(hipMemsetAsync(buf.p, 0, (size_t)fr.cover_words * 4, nullptr));
+    HIP_TRY(buf.ensure((size_t)fr.cover_bytes));
+    fr.cover = buf.as<uint8_t>();
+    HIP_TRY(hipMemsetAsync(buf.p, 0, (size_t)fr.cover_bytes, nullptr));
     rrt::launch_cover(s->dmeshes[(size_t)mi], s->cover[(size_t)slot].second, fr, 0, nullptr);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(words, buf.p, (size_t)fr.cover_words * 4, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> cells((size_t)fr.cover_bytes);
+    HIP_TRY(hipMemcpy(cells.data(), buf.p, cells.size(), hipMemcpyDeviceToHost));
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x) pixels[(size_t)y * width + x] = cells[(size_t)y * fr.cover_stride + x / rrt::kCoverCell] ? 1 : 0;
+    *every = cells[(size_t)fr.cover_bytes - 8] ? 1 : 0;
     return RRT_OK;
 }
 

@@ -143,10 +143,14 @@ constexpr int32_t kTreeStaleBoxes = 1;
 // triangle of this mesh?" has a conservative per-frame answer: k_cover projects every triangle (dilated by the same
 // acceptance bound the conservative cull uses) onto the image and sets the pixels of its bounding rectangle; a
 // primary ray whose pixel is clear skips Entity::collide of that mesh -- root box, set-up, walk -- with the miss
-// the walk would have returned.  One bit per pixel, rows of DFrame::cover_stride words, one trailing word that says
-// "treat every pixel as set" (a triangle at or behind the eye plane); up to kMaxCover meshes of a scene carry one.
+// the walk would have returned.  One BYTE per cell of kCoverCell x 1 pixels (bytes, so that k_cover can set them with
+// plain stores -- every writer writes the same 1 -- instead of read-modify-write atomics; four pixels of a row, which
+// is what a wave of the primary kernel covers at 16 samples a pixel), rows of DFrame::cover_stride bytes (a multiple
+// of 8: a 32-pixel tile row is one aligned 8-byte word), then 8 trailing bytes whose first says "treat every cell as
+// set" (a triangle at or behind the eye plane); up to kMaxCover meshes of a scene carry one.
 constexpr int32_t kCoverShift = 8;
 constexpr int32_t kMaxCover = 4;
+constexpr int32_t kCoverCell = 4;
 constexpr int32_t kCoverMinEntries = 256;   // smaller meshes are not worth a mask (their walk is a handful of leaves)
 
 struct DScene {
@@ -219,9 +223,9 @@ struct DFrame {
     uint32_t s0, ns;         // first sample / samples in this batch
     uint32_t tile_skew;      // tile_skew(tiles_x, tile_world): row ty of the tile grid is rotated by tile_skew * ty columns
     uint32_t pack_log2;      // a wave of the primary kernel = 64 >> pack_log2 pixels x (1 << pack_log2) samples of this batch
-    // coverage masks of this frame (see kMaxCover): n_cover masks of cover_words words each, or n_cover = 0
-    const uint32_t* cover;
-    uint32_t n_cover, cover_stride, cover_words;
+    // coverage masks of this frame (see kMaxCover): n_cover masks of cover_bytes bytes each, or n_cover = 0
+    const uint8_t* cover;
+    uint32_t n_cover, cover_stride, cover_bytes;
     // Tile bins of this frame, or nullptr: one 64-bit word per 32x8-pixel tile of the image (row-major over the tile
     // grid), bit e clear = no primary ray through that tile can be answered by entity e (a sphere whose projected
     // bounds miss the tile, a mesh whose coverage mask is clear over it).  Scenes of at most 64 entities.

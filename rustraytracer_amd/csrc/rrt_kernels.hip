@@ -651,7 +651,7 @@ constexpr NoLds kNoLds{};
 // select chains.  From LDS they arrive where they are used, as VGPR operands: indices in doubles.
 constexpr int32_t kCLightDir = 0, kCLightColor = 3, kCIntensity = 6, kCAmbient = 7, kCEye = 8, kCLensZ = 11,
                   kCLensW = 12, kCLensH = 13, kCFaces = 14 /* 6 x {ptr, w, h}: 2 doubles each */,
-                  kCCover = 26 /* {ptr, n_cover, cover_stride, cover_words, -}: 3 doubles */, kCDoubles = 29;
+                  kCCover = 26 /* {ptr, n_cover, cover_stride, cover_bytes, -}: 3 doubles */, kCDoubles = 29;
 RRT_DEV V3 ld3l(const RRT_LDS double* p) { return V3{p[0], p[1], p[2]}; }
 
 // Per-lane read of a field of an LDS-staged struct (the record index differs per lane).
@@ -1239,14 +1239,14 @@ RRT_DEV uint32_t cover_bits(LDS lds, uint32_t x, uint32_t y) {
         const RRT_LDS uint32_t* cv = (const RRT_LDS uint32_t*)(lds.consts + kCCover);
         const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cv[2]);
         if (n != 0u) {
-            const RRT_GLOBAL uint32_t* m = as_global(lds_field<const uint32_t*>(cv, 0));
-            const uint32_t stride = cv[3], words = cv[4];
-            const uint32_t at = y * stride + (x >> 5);
+            const RRT_GLOBAL uint8_t* m = as_global(lds_field<const uint8_t*>(cv, 0));
+            const uint32_t stride = cv[3], bytes = cv[4];
+            const uint32_t at = y * stride + (x >> 2);
 #pragma unroll
             for (uint32_t k = 0; k < (uint32_t)kMaxCover; ++k) {
                 if (k < n) {
-                    const uint32_t w = m[k * words + at], all = m[k * words + words - 1u];
-                    if ((((w >> (x & 31u)) | all) & 1u) == 0u) cov &= ~(1u << k);
+                    const uint32_t c = m[k * bytes + at], all = m[k * bytes + bytes - 8u];
+                    if ((c | all) == 0u) cov &= ~(1u << k);
                 }
             }
         }
@@ -1488,7 +1488,7 @@ RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned 
             RRT_LDS uint32_t* cv = (RRT_LDS uint32_t*)(c + kCCover);
             const uint64_t cp = (uint64_t)fr.cover;
             cv[0] = (uint32_t)cp; cv[1] = (uint32_t)(cp >> 32);
-            cv[2] = fr.cover ? fr.n_cover : 0u; cv[3] = fr.cover_stride; cv[4] = fr.cover_words; cv[5] = 0u;
+            cv[2] = fr.cover ? fr.n_cover : 0u; cv[3] = fr.cover_stride; cv[4] = fr.cover_bytes; cv[5] = 0u;
         }
         st.consts = c;
     }
@@ -1817,10 +1817,38 @@ __global__ __launch_bounds__(256) void k_accumulate_quad(DWork wk, DFrame fr, ui
 struct CoverParams {
     double eye[3], lens_z, lens_w, lens_h;
     double delta, z_near;
-    uint32_t width, height, stride, words;
+    uint32_t width, height, stride, bytes;
 };
-__global__ __launch_bounds__(256) void k_cover(const DTri* tris, int32_t n, CoverParams p, uint32_t* mask) {
-    const int32_t j = (int32_t)(blockIdx.x * 256u + threadIdx.x);
+// cells [c0, c1] of row y, as bytes (a cell = kCoverCell pixels of a row).  Plain stores of the value 1: every writer
+// writes the same thing, so nothing is read, nothing is atomic and nothing waits.  (The first version kept a bit per
+// pixel and OR-ed it in: device-scope atomics are performed at the memory side of the eight XCDs' L2s, one after the
+// other per address -- 90 us for the UFO's 9 825 entries, 2.6 ms for the 2 M-triangle field.)
+// A run is written as (possibly overlapping, possibly unaligned) windows of 8, 4, 2 or 1 bytes that stay inside it:
+// at most two stores up to 8 cells, one per 8 cells beyond -- a wave's scattered stores are what this kernel's time is.
+RRT_DEV void cover_row(uint8_t* mask, const CoverParams& p, int32_t y, int32_t c0, int32_t c1) {
+    typedef uint64_t u64u __attribute__((aligned(1)));
+    typedef uint32_t u32u __attribute__((aligned(1)));
+    typedef uint16_t u16u __attribute__((aligned(1)));
+    uint8_t* row = mask + (size_t)y * p.stride;
+    const int32_t len = c1 - c0 + 1;
+    if (len >= 8) {
+        for (int32_t c = c0; c + 7 < c1; c += 8) *(u64u*)(row + c) = 0x0101010101010101ull;
+        *(u64u*)(row + c1 - 7) = 0x0101010101010101ull;
+    } else if (len >= 4) {
+        *(u32u*)(row + c0) = 0x01010101u; *(u32u*)(row + c1 - 3) = 0x01010101u;
+    } else if (len >= 2) {
+        *(u16u*)(row + c0) = 0x0101u; *(u16u*)(row + c1 - 1) = 0x0101u;
+    } else if (len == 1) {
+        row[c0] = 1;
+    }
+}
+// Several lanes per triangle, each taking every n-th row of the rectangle: with one lane per triangle the
+// kernel lasted as long as its slowest lane's few hundred scattered byte stores (186 us on the UFO: 154 waves).
+// (2^lanes_log2 lanes: 8 for meshes like the UFO, 1 from a million entries on, where triangles are a few pixels and the
+// projection itself is the work: 0.20 against 0.72 ms on the 2 M-triangle field.)
+__global__ __launch_bounds__(256) void k_cover(const DTri* tris, int32_t n, CoverParams p, uint8_t* mask, uint32_t lanes_log2) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x, kCoverLanes = 1u << lanes_log2;
+    const int32_t j = (int32_t)(gid >> lanes_log2), sub = (int32_t)(gid & (kCoverLanes - 1u));
     bool big = false;
     int32_t x0 = 0, x1 = -1, y0 = 0, y1 = -1;
     if (j < n) {
@@ -1847,30 +1875,22 @@ __global__ __launch_bounds__(256) void k_cover(const DTri* tris, int32_t n, Cove
                 y0 = (int32_t)floor(fmax(pylo, 0.0)); y1 = (int32_t)floor(fmin(pyhi, (double)p.height - 1.0));
             }
         }
-        if (all) atomicOr(&mask[p.words - 1u], 1u);
-        big = x1 >= x0 && y1 >= y0 && (int64_t)((x1 >> 5) - (x0 >> 5) + 1) * (y1 - y0 + 1) > 16;
-        if (!big) {
-            for (int32_t y = y0; y <= y1; ++y)
-                for (int32_t wx = x0 >> 5; wx <= (x1 >> 5); ++wx) {
-                    const uint32_t lo = wx == (x0 >> 5) ? (uint32_t)x0 & 31u : 0u, hi = wx == (x1 >> 5) ? (uint32_t)x1 & 31u : 31u;
-                    const uint32_t bits = (0xffffffffu >> (31u - hi)) & (0xffffffffu << lo);
-                    uint32_t* w = mask + (size_t)y * p.stride + wx;
-                    if ((*w & bits) != bits) atomicOr(w, bits);
-                }
-        }
+        if (all) mask[p.bytes - 8u] = 1;
+        x0 /= kCoverCell; x1 = x1 >= 0 ? x1 / kCoverCell : -1;          // pixels -> cells
+        big = x1 >= x0 && y1 >= y0 && (int64_t)(x1 - x0 + 1) * (y1 - y0 + 1) > (2048 << lanes_log2);
+        if (!big)
+            for (int32_t y = y0 + sub; y <= y1; y += (int32_t)kCoverLanes) cover_row(mask, p, y, x0, x1);
+        big = big && sub == 0;
     }
-    // rectangles of more than 16 words: the wave fills them together, one after the other
+    // rectangles of more than 2048 cells per lane (a triangle that fills a good part of the image): the wave fills them
+    // together, one after the other -- lane l takes rows l / 8 (mod 8) and the 8-cell pieces l % 8 (mod 8) of a row
+    // (measured: with every rectangle above 16 words on this path the UFO's masks took 27 us instead of 9)
     for (unsigned long long todo = __ballot(big); todo != 0ull; todo &= todo - 1ull) {
         const int src = __ffsll((long long)todo) - 1;
         const int32_t bx0 = __shfl(x0, src, 64), bx1 = __shfl(x1, src, 64), by0 = __shfl(y0, src, 64), by1 = __shfl(y1, src, 64);
-        const int32_t wx0 = bx0 >> 5, nwx = (bx1 >> 5) - wx0 + 1, total = nwx * (by1 - by0 + 1);
-        for (int32_t i = (int32_t)(threadIdx.x & 63u); i < total; i += 64) {
-            const int32_t y = by0 + i / nwx, wx = wx0 + i % nwx;
-            const uint32_t lo = wx == (bx0 >> 5) ? (uint32_t)bx0 & 31u : 0u, hi = wx == (bx1 >> 5) ? (uint32_t)bx1 & 31u : 31u;
-            const uint32_t bits = (0xffffffffu >> (31u - hi)) & (0xffffffffu << lo);
-            uint32_t* w = mask + (size_t)y * p.stride + wx;
-            if ((*w & bits) != bits) atomicOr(w, bits);
-        }
+        const int32_t l = (int32_t)(threadIdx.x & 63u);
+        for (int32_t y = by0 + (l >> 3); y <= by1; y += 8)
+            for (int32_t c = bx0 + 8 * (l & 7); c <= bx1; c += 64) cover_row(mask, p, y, c, c + 7 > bx1 ? bx1 : c + 7);
     }
 }
 
@@ -1884,8 +1904,8 @@ struct BinParams {
     double eye[3], lens_z, lens_w, lens_h, z_slack;
     uint32_t width, height, tiles_x, tiles_y;
 };
-__global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint32_t* cover, uint32_t n_cover, uint32_t stride,
-                                              uint32_t words, uint64_t* bins) {
+__global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint8_t* cover, uint32_t n_cover, uint32_t stride,
+                                              uint32_t bytes, uint64_t* bins) {
     const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
     if (tile >= p.tiles_x * p.tiles_y) return;
     const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
@@ -1915,10 +1935,12 @@ __global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint
         } else if (kind == 1) {
             const int32_t cs = (sc.meshes[ent.index].flags >> kCoverShift) & 15;
             if (cs != 0 && (uint32_t)cs <= n_cover) {
-                const uint32_t* m = cover + (size_t)(cs - 1) * words;
-                uint32_t any = m[words - 1u];
-                for (uint32_t y = ty * RRT_TILE_H; y < (ty + 1u) * RRT_TILE_H && y < p.height; ++y) any |= m[y * stride + tx];
-                may = any != 0u;
+                // a tile row = 32 pixels = 8 cells = one aligned 8-byte word of the mask
+                const uint8_t* m = cover + (size_t)(cs - 1) * bytes;
+                uint64_t any = *(const uint64_t*)(m + bytes - 8u);
+                for (uint32_t y = ty * RRT_TILE_H; y < (ty + 1u) * RRT_TILE_H && y < p.height; ++y)
+                    any |= *(const uint64_t*)(m + (size_t)y * stride + 8u * tx);
+                may = any != 0ull;
             }
         }
         if (!may) bits &= ~(1ull << e);
@@ -2107,12 +2129,14 @@ void launch_cover(const DMesh& mesh, int32_t n_entries, const DFrame& fr, uint32
     p.delta = 2.0 * (2.5e-7 * S * S * 1.7320508075688774 * (R + S)) * 1.000001 + 1e-9 * (omax + mesh.abs_max) + 1e-300;
     const double dt = 2.0 * (8e-8 * S * S * (R + S)) * 1.000001;
     p.z_near = 2.0 * dt + 1e-9 * (omax + mesh.abs_max) + 1e-300;
-    p.width = fr.width; p.height = fr.height; p.stride = fr.cover_stride; p.words = fr.cover_words;
-    hipLaunchKernelGGL(k_cover, dim3(((uint32_t)n_entries + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, mesh.tris, n_entries, p,
-                       const_cast<uint32_t*>(fr.cover) + (size_t)slot * fr.cover_words);
+    p.width = fr.width; p.height = fr.height; p.stride = fr.cover_stride; p.bytes = fr.cover_bytes;
+    const uint32_t lanes_log2 = n_entries >= (1 << 20) ? 0u : 3u;
+    const uint64_t threads = (uint64_t)n_entries << lanes_log2;
+    hipLaunchKernelGGL(k_cover, dim3((uint32_t)((threads + 255u) / 256u)), dim3(256), 0, (hipStream_t)stream, mesh.tris, n_entries, p,
+                       const_cast<uint8_t*>(fr.cover) + (size_t)slot * fr.cover_bytes, lanes_log2);
 }
 void launch_bins(const DScene& sc, const DFrame& fr, void* stream) {
-    static_assert(RRT_TILE_W == 32, "a tile is one mask word wide");
+    static_assert(RRT_TILE_W == 8 * kCoverCell, "a tile row is one 8-byte word of the mask");
     BinParams p{};
     double omax = 0.0;
     for (int a = 0; a < 3; ++a) {
@@ -2124,7 +2148,7 @@ void launch_bins(const DScene& sc, const DFrame& fr, void* stream) {
     p.width = fr.width; p.height = fr.height; p.tiles_x = fr.tiles_x; p.tiles_y = fr.tiles_y;
     const uint32_t n = fr.tiles_x * fr.tiles_y;
     hipLaunchKernelGGL(k_bins, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, sc, p, fr.cover, fr.cover ? fr.n_cover : 0u,
-                       fr.cover_stride, fr.cover_words, const_cast<uint64_t*>(fr.tile_bins));
+                       fr.cover_stride, fr.cover_bytes, const_cast<uint64_t*>(fr.tile_bins));
 }
 void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream) {
     const uint32_t tiles_x = (w + RRT_TILE_W - 1) / RRT_TILE_W, tiles_y = (h + RRT_TILE_H - 1) / RRT_TILE_H;

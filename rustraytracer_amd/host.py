@@ -173,13 +173,12 @@ class World:
         return out
 
     def cover_mask(self, ent, width, height, camera=None):
-        """The primary-ray coverage mask of mesh entity `ent` (rrt_cover_mask) as a bool image + the "all" flag."""
+        """The primary-ray coverage mask of mesh entity `ent` (rrt_cover_mask) as a bool image + the "every pixel" flag."""
         cam = camera or default_camera()
-        stride = (width + 31) // 32
-        words = np.zeros(stride * height + 1, np.uint32)
-        B.check(B.lib.rrt_cover_mask(self.h, C.byref(cam), width, height, ent, _ptr(words)))
-        bits = np.unpackbits(words[:-1].reshape(height, stride).view(np.uint8), axis=1, bitorder="little")[:, :width]
-        return bits.astype(bool), bool(words[-1])
+        px = np.zeros((height, width), np.uint8)
+        every = C.c_int(0)
+        B.check(B.lib.rrt_cover_mask(self.h, C.byref(cam), width, height, ent, _ptr(px), C.byref(every)))
+        return px.astype(bool), bool(every.value)
 
     def trace_rays(self, rays):
         rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
