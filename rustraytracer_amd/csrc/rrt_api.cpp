@@ -103,7 +103,7 @@ struct TimedLaunch {
 
 struct WorkSet {
     hipStream_t stream = nullptr;
-    DevBuf w_q[2], w_qcount, w_rec, w_samp, w_samp32, w_accum, w_stats, w_cover, w_bins;
+    DevBuf w_q[2], w_rec, w_samp, w_samp32, w_accum, w_zero, w_bins;   // w_zero: what a frame starts from zero, see zero_layout
     // timing and counters of the last frame rendered with this set
     std::vector<TimedLaunch> timed;
     size_t timed_used = 0;
@@ -603,30 +603,37 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
 
 uint64_t cover_stride(uint32_t width) { return ((uint64_t)(width + rrt::kCoverCell - 1) / rrt::kCoverCell + 7) / 8 * 8; }
 uint64_t cover_bytes(const rrt::DFrame& fr) { return (uint64_t)fr.n_cover * fr.cover_bytes; }
+// What every frame starts from zero sits in ONE block, so that it is one memset (each is a ~4 us kernel in the frame's
+// launch chain): the statistics, the queue counters (zeroed again in front of every further batch) and the coverage masks.
+constexpr uint64_t kStatsBytes = 8 * 8, kQCountBytes = 2 * (rrt::kMaxLevels + 1) * 4;
+uint64_t zero_bytes(const rrt::DFrame& fr) { return 256 + cover_bytes(fr); }
+static_assert(kStatsBytes + kQCountBytes <= 256, "statistics and queue counters share the block's first 256 bytes");
+void zero_layout(unsigned char* base, FramePlan& pl, rrt::DWork* wk) {
+    wk->stats = (unsigned long long*)base;
+    wk->q_count = (uint32_t*)(base + kStatsBytes);
+    pl.fr.cover = pl.fr.n_cover ? base + 256 : nullptr;
+}
 uint64_t bins_bytes(const rrt::DFrame& fr, bool want) { return want ? (uint64_t)fr.tiles_x * fr.tiles_y * 8 : 0; }
 
 int ensure_work(WorkSet* s, FramePlan& pl, rrt::DWork* wk) {
     const uint64_t P = pl.cap;
-    if (pl.fr.n_cover) HIP_TRY(s->w_cover.ensure(cover_bytes(pl.fr)));
-    pl.fr.cover = pl.fr.n_cover ? s->w_cover.as<uint8_t>() : nullptr;
+    HIP_TRY(s->w_zero.ensure(zero_bytes(pl.fr)));
+    zero_layout((unsigned char*)s->w_zero.p, pl, wk);
     if (pl.want_bins) HIP_TRY(s->w_bins.ensure(bins_bytes(pl.fr, true)));
     pl.fr.tile_bins = pl.want_bins ? s->w_bins.as<uint64_t>() : nullptr;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(s->w_q[i].ensure(P * rrt::kRecDoubles * 8));
         wk->q[i] = s->w_q[i].as<double>();
     }
-    HIP_TRY(s->w_qcount.ensure(2 * (rrt::kMaxLevels + 1) * 4));
     HIP_TRY(s->w_rec.ensure(P * rrt::kRecDoubles * 8 * pl.levels));
     HIP_TRY(s->w_samp.ensure(P * 3 * 8));
     HIP_TRY(s->w_samp32.ensure(P * 4));
     HIP_TRY(s->w_accum.ensure((size_t)pl.fr.npx_local * 3 * 8));
-    HIP_TRY(s->w_stats.ensure(8 * 8));
-    wk->q_count = s->w_qcount.as<uint32_t>();
+
     wk->rec = s->w_rec.as<double>();
     wk->samp = s->w_samp.as<double>();
     wk->samp32 = s->w_samp32.as<uint32_t>();
     wk->accum = s->w_accum.as<double>();
-    wk->stats = s->w_stats.as<unsigned long long>();
     wk->cap = P;
     return RRT_OK;
 }
@@ -636,9 +643,9 @@ int ensure_work(WorkSet* s, FramePlan& pl, rrt::DWork* wk) {
 constexpr uint64_t kCarveAlign = 256;
 uint64_t carve_bytes(const FramePlan& pl) {
     const uint64_t P = pl.cap;
-    const uint64_t parts[] = {8 * 8, 2 * (rrt::kMaxLevels + 1) * 4, P * rrt::kRecDoubles * 8, P * rrt::kRecDoubles * 8,
+    const uint64_t parts[] = {zero_bytes(pl.fr), P * rrt::kRecDoubles * 8, P * rrt::kRecDoubles * 8,
                               P * rrt::kRecDoubles * 8 * pl.levels, P * 3 * 8, P * 4, (uint64_t)pl.fr.npx_local * 3 * 8,
-                              cover_bytes(pl.fr), bins_bytes(pl.fr, pl.want_bins)};
+                              bins_bytes(pl.fr, pl.want_bins)};
     uint64_t total = 0;
     for (uint64_t b : parts) total += (b + kCarveAlign - 1) / kCarveAlign * kCarveAlign;
     return total;
@@ -653,15 +660,13 @@ int carve_work(unsigned char* base, uint64_t bytes, FramePlan& pl, rrt::DWork* w
         off += (b + kCarveAlign - 1) / kCarveAlign * kCarveAlign;
         return p;
     };
-    wk->stats = (unsigned long long*)take(8 * 8);
-    wk->q_count = (uint32_t*)take(2 * (rrt::kMaxLevels + 1) * 4);
+    zero_layout(take(zero_bytes(pl.fr)), pl, wk);
     wk->q[0] = (double*)take(P * rrt::kRecDoubles * 8);
     wk->q[1] = (double*)take(P * rrt::kRecDoubles * 8);
     wk->rec = (double*)take(P * rrt::kRecDoubles * 8 * pl.levels);
     wk->samp = (double*)take(P * 3 * 8);
     wk->samp32 = (uint32_t*)take(P * 4);
     wk->accum = (double*)take((uint64_t)pl.fr.npx_local * 3 * 8);
-    pl.fr.cover = pl.fr.n_cover ? (const uint8_t*)take(cover_bytes(pl.fr)) : nullptr;
     pl.fr.tile_bins = pl.want_bins ? (const uint64_t*)take(bins_bytes(pl.fr, true)) : nullptr;
     wk->cap = P;
     return RRT_OK;
@@ -754,10 +759,9 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     ws->frame_timed = timed;
     ws->stats_src = wk.stats;
     if (timed) HIP_TRY(hipEventRecord(ws->ev_begin, stream));
-    HIP_TRY(hipMemsetAsync(wk.stats, 0, 8 * 8, stream));
+    HIP_TRY(hipMemsetAsync(wk.stats, 0, zero_bytes(pl.fr), stream));      // statistics, queue counters, coverage masks
     rrt::DFrame fr = pl.fr;
     if (fr.n_cover) {
-        HIP_TRY(hipMemsetAsync(const_cast<uint8_t*>(fr.cover), 0, cover_bytes(fr), stream));
         for (uint32_t k = 0; k < fr.n_cover; ++k)
             rrt::launch_cover(s->dmeshes[(size_t)s->cover[k].first], s->cover[k].second, fr, k, stream);
     }
@@ -766,7 +770,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         fr.s0 = b * pl.batch_spp;
         fr.ns = std::min(pl.batch_spp, st->spp - fr.s0);
         fr.pack_log2 = sample_pack_log2(fr.ns);
-        HIP_TRY(hipMemsetAsync(wk.q_count, 0, 2 * (rrt::kMaxLevels + 1) * 4, stream));
+        if (b > 0) HIP_TRY(hipMemsetAsync(wk.q_count, 0, kQCountBytes, stream));
         TimedLaunch* tl = nullptr;
         if (timed_kernels) {
             rc = timed_slot(ws, &tl);
