@@ -565,7 +565,9 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
     fr.tile_skew = rrt::tile_skew(fr.tiles_x, st->tile_world);
     fr.n_slots = (uint32_t)((n_tiles + st->tile_world - 1) / st->tile_world);
     fr.npx_local = fr.n_slots * 256u;
-    out->levels = st->max_bounce + 2;
+    // level records are written by the casts that continue: depths 0 .. max_bounce (a cast at depth max_bounce + 1
+    // never does, tracer.rs:205), i.e. max_bounce + 1 levels -- round 1 allocated one more, 56 B per path unused
+    out->levels = st->max_bounce + 1;
     const size_t bpp = bytes_per_path(out->levels);
     const uint64_t fixed = fixed_per_px * fr.npx_local;
     uint64_t max_spp = budget > fixed ? (budget - fixed) / ((uint64_t)bpp * fr.npx_local) : 0;
