@@ -264,7 +264,7 @@ int rrt_render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* s
  * library runs on holds until the process ends.
  *   - the scene must be committed (rrt_scene_commit) and unchanged since: otherwise RRT_E_STATE;
  *   - the frame must fit: local pixels x (24 + bytes per path of ONE sample) <= the scratch, i.e.
- *     about 690 k pixels per rank at max_bounce 2 (960x540 whole; 1080p from tile_world 4 up);
+ *     about 800 k pixels per rank at max_bounce 2 (960x540 whole; 1080p from tile_world 3 up);
  *     larger frames return RRT_E_NOMEM with the sizes in rrt_last_error().  spp is not limited:
  *     samples are processed in as many batches as the scratch requires;
  *   - all calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two

@@ -79,7 +79,7 @@ def test_noalloc_sharded_frame_and_limits(H, scenes):
     assert B.lib.rrt_render_device_noalloc(g.h, C.byref(cam), C.byref(st), out.data_ptr(), None, None, None, None) == -3
     assert b"committed" in B.lib.rrt_last_error()
     g.commit()
-    # 1080p does not fit whole (2.07 M pixels x 388 B > 256 MiB): a clear error, nothing launched
+    # 1080p does not fit whole (2.07 M pixels x 332 B > 256 MiB): a clear error, nothing launched
     st = H.make_settings(1920, 1080, spp=2)
     big = torch.zeros((1080, 1920, 3), dtype=torch.uint8, device="cuda:0")
     assert B.lib.rrt_render_device_noalloc(g.h, C.byref(cam), C.byref(st), big.data_ptr(), None, None, None, None) == -4
