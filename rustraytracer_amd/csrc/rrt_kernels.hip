@@ -41,6 +41,9 @@ namespace {
 #ifndef RRT_ABL
 #define RRT_ABL 0
 #endif
+#ifndef RRT_PHILOX_VKEYS
+#define RRT_PHILOX_VKEYS 1
+#endif
 #ifndef RRT_XCD_ORDER
 #define RRT_XCD_ORDER 1
 #endif
@@ -119,6 +122,12 @@ RRT_DEV uint32_t sat_u32(double v) {
 
 __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t out[4]) {
+#if defined(__HIP_DEVICE_COMPILE__) && RRT_PHILOX_VKEYS
+    // The key schedule is wave-uniform (seed + round * constant), so the compiler keeps all twenty round keys in SGPRs --
+    // which this kernel does not have: they were spilled to VGPR lanes and read back with v_readlane (+ hazard nops)
+    // in every round.  Made opaque per-lane values here, a round's keys are two v_add_u32 with a literal.
+    asm volatile("" : "+v"(k0), "+v"(k1));
+#endif
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
@@ -2053,7 +2062,7 @@ inline uint32_t trace_grid() {
     static const uint32_t g = [] {
         const char* e = getenv("RRT_TRACE_GRID");
         const long v = e ? atol(e) : 0;
-        return (uint32_t)(v > 0 && v <= 65535 ? v : 256 * 64);
+        return (uint32_t)(v > 0 && v <= 65535 ? v : 256 * 128);   // the cap; launch_primary sizes the grid by the chunk count
     }();
     return g;
 }
@@ -2090,7 +2099,8 @@ inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) 
 
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
     // about eight 256-path chunks per persistent block (the per-block LDS staging is then ~3 % of its work; measured
-    // on the full cfg2 frame, 130 k chunks: 4096 blocks 1.63 ms, 8192 1.51, 16384 1.47, 32768 1.51), a multiple of 8
+    // on the full cfg2 frame, 130 k chunks: 4096 blocks 1.63 ms, 8192 1.51, 16384 1.47, 32768 1.51; on the height field's
+    // 259 k chunks: 16384 blocks 57.0 ms, 32768 56.5), a multiple of 8
     // for the XCD-aware order, at least 2048 blocks so that a small launch still fills the chip
     const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
     uint64_t want = (chunks / 8 + 2047) / 2048 * 2048;      // in steps of 2048 blocks = two rounds of resident blocks
