@@ -212,7 +212,7 @@ int rrt_set_shadow_mode(rrt_scene* s, int mode);
 int rrt_translate_entity(rrt_scene* s, int entity, const double delta[3], int refit);
 
 /* Upper bound in bytes for per-render wavefront work buffers (queues, path
- * records, sample buffer).  Default 32 GiB. */
+ * records, sample buffer).  Default 48 GiB (per stream the scene renders on). */
 int rrt_set_work_budget(rrt_scene* s, uint64_t bytes);
 
 /* Conservative triangle cull inside the kd leaves (no reference counterpart; results are

@@ -146,7 +146,7 @@ struct rrt_scene {
     bool has_light = false;
     double light_dir[3] = {0, 0, 0}, light_color[3] = {0, 0, 0}, light_intensity = 0.0;
     double ambient = 0.15;  // tracer.rs:73
-    uint64_t work_budget = 32ull << 30;   // of 288 GB; a batch is also capped by 32-bit record offsets (76.7 M paths = 27.9 GB)
+    uint64_t work_budget = 48ull << 30;   // of 288 GB, per stream a scene renders on; a batch is also capped at 178.9 M paths (plan_frame)
     int cull_mode = 1;
     int timing = 2;        // rrt_set_timing: 0 no events, 1 frame begin/end, 2 + per-kernel pairs
 
@@ -575,18 +575,28 @@ int plan_frame(const rrt_scene* s, const rrt_camera* cam, const rrt_settings* st
     if (max_spp == 0)
         return fail(RRT_E_NOMEM, "work budget too small for one sample per pixel: " + std::to_string(fr.npx_local) +
                                      " pixels x " + std::to_string(bpp + fixed_per_px) + " B > " + std::to_string(budget) + " B");
-    // keep a path's byte offset in the work arrays (56 * path id) in 32 bits: the kernels address them that way
-    max_spp = std::min<uint64_t>(max_spp, (0xffffffffull / (rrt::kRecDoubles * 8)) / fr.npx_local);
+    // keep a path's byte offset in the sample arrays (24 * path id) in 32 bits: the kernels address them that way
+    // (178.9 M paths; the 56-byte records and queue entries are addressed in 64 bits, rrt_kernels.hip: at_rec)
+    max_spp = std::min<uint64_t>(max_spp, (0xffffffffull / 24) / fr.npx_local);
     if (max_spp == 0) return fail(RRT_E_NOMEM, "frame too large");
     out->n_batches = (uint32_t)((st->spp + max_spp - 1) / max_spp);
     out->batch_spp = (st->spp + out->n_batches - 1) / out->n_batches;
     if (out->n_batches > 1 && !st->batch_spp) {
-        // Sample packing (sample_pack_log2) wants a batch's sample count to be a multiple of a power of two: batches
-        // of the largest multiple of 16 (8, 4, 2 when fewer fit) under the budget, and the remainder last.
-        uint64_t unit = 16;
-        while (unit > max_spp) unit >>= 1;
-        out->batch_spp = (uint32_t)(max_spp / unit * unit);
-        out->n_batches = (st->spp + out->batch_spp - 1) / out->batch_spp;
+        // Sample packing (sample_pack_log2) wants a batch's sample count to be a multiple of a large power of two
+        // (height field: 8 samples of a pixel a wave 2.70 Grays/s, 16: 3.00, 32: 3.25, 64: 3.71), and every batch has a
+        // fixed cost: the largest unit of 64, 32, ... whose multiples under the budget need at most half as many
+        // batches again as the fewest possible; the remainder goes last.
+        const uint64_t n_min = out->n_batches;
+        for (uint64_t unit = 64; unit >= 1; unit >>= 1) {
+            const uint64_t b = max_spp / unit * unit;
+            if (b == 0) continue;
+            const uint64_t n = (st->spp + b - 1) / b;
+            if (2 * n <= 3 * n_min || unit == 1) {
+                out->batch_spp = (uint32_t)b;
+                out->n_batches = (uint32_t)n;
+                break;
+            }
+        }
     }
     out->cap = (uint64_t)out->batch_spp * fr.npx_local;
     // pixels this rank really owns

@@ -1115,23 +1115,44 @@ RRT_DEV void continuation(const DFrame& fr, const DMaterial& m, V3 pos, V3 n, V3
 // lane) + immediate: one scalar base per array and one VGPR offset serve all fields of a record.
 // With one array per field (SoA) every access carried its own 64-bit address and base pointer --
 // 15 SGPR pairs for the stores of a continuing path, in a kernel that is short of SGPRs.
-// plan_frame keeps 56 * (paths per batch) below 2^32.
+// plan_frame keeps 24 * (paths per batch) below 2^32 (sample colours; the 56-byte records: see at_rec).
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 template <class T, class B>
 RRT_DEV T& at_off(B* base, uint32_t byte_off) { return *(T*)((char*)base + byte_off); }
 constexpr uint32_t kDeadSky = 0x80000000u;     // queue entry, path word: the cast that spawned this ray has mix() == +-0.0
 constexpr uint32_t kSampTexel = 0x01000000u;   // samp32 tag: the low 24 bits are a sky texel (else: the colour is in samp)
-// level record {A.xyz, Pm.xyz, mixR}
-RRT_DEV void st_rec(double* level_base, uint32_t off, V3 A, V3 Pm, double mixR) {
-    at_off<f64x2>(level_base, off) = f64x2{A.x, A.y};
-    at_off<f64x2>(level_base, off + 16u) = f64x2{A.z, Pm.x};
-    at_off<f64x2>(level_base, off + 32u) = f64x2{Pm.y, Pm.z};
-    at_off<double>(level_base, off + 48u) = mixR;
+// The 56-byte records (level records, queue entries) of a batch of more than 2^32 / 56 = 76.7 M paths do not fit a
+// 32-bit byte offset.  Record `uidx + lidx`: uidx is the wave-uniform part of the index (the compiler keeps
+// base + 56 uidx in SGPRs: scalar arithmetic), lidx the lane's (56 lidx is the 32-bit VGPR offset, as before); with
+// uidx = 0 and a per-lane index the address is formed per lane in 64 bits (one v_mad_u64_u32).
+constexpr uint32_t kRecBytes = (uint32_t)(kRecDoubles * 8);
+template <class T, class B>
+RRT_DEV T& at_rec(B* base, uint32_t uidx, uint32_t lidx, uint32_t field) {
+    return *(T*)((char*)base + (uint64_t)uidx * kRecBytes + (uint32_t)(lidx * kRecBytes + field));
 }
-RRT_DEV void ld_rec(double* level_base, uint32_t off, V3* A, V3* Pm, double* mixR) {
-    const f64x2 a = at_off<f64x2>(level_base, off), b = at_off<f64x2>(level_base, off + 16u),
-                c = at_off<f64x2>(level_base, off + 32u);
-    *mixR = at_off<double>(level_base, off + 48u);
+template <class T, class B>
+RRT_DEV T& at_rec(B* base, uint32_t idx, uint32_t field) {
+    return *(T*)((char*)base + ((uint64_t)idx * kRecBytes + field));
+}
+// level record {A.xyz, Pm.xyz, mixR}; UNI: the record index is uidx + lidx with uidx wave-uniform and 56 lidx < 2^32
+template <bool UNI>
+RRT_DEV void st_rec(double* level_base, uint32_t uidx, uint32_t lidx, V3 A, V3 Pm, double mixR) {
+    if (UNI) {
+        at_rec<f64x2>(level_base, uidx, lidx, 0u) = f64x2{A.x, A.y};
+        at_rec<f64x2>(level_base, uidx, lidx, 16u) = f64x2{A.z, Pm.x};
+        at_rec<f64x2>(level_base, uidx, lidx, 32u) = f64x2{Pm.y, Pm.z};
+        at_rec<double>(level_base, uidx, lidx, 48u) = mixR;
+    } else {
+        at_rec<f64x2>(level_base, uidx + lidx, 0u) = f64x2{A.x, A.y};
+        at_rec<f64x2>(level_base, uidx + lidx, 16u) = f64x2{A.z, Pm.x};
+        at_rec<f64x2>(level_base, uidx + lidx, 32u) = f64x2{Pm.y, Pm.z};
+        at_rec<double>(level_base, uidx + lidx, 48u) = mixR;
+    }
+}
+RRT_DEV void ld_rec(double* level_base, uint32_t idx, V3* A, V3* Pm, double* mixR) {
+    const f64x2 a = at_rec<f64x2>(level_base, idx, 0u), b = at_rec<f64x2>(level_base, idx, 16u),
+                c = at_rec<f64x2>(level_base, idx, 32u);
+    *mixR = at_rec<double>(level_base, idx, 48u);
     *A = mk(a.x, a.y, b.x);
     *Pm = mk(b.y, c.x, c.y);
 }
@@ -1277,11 +1298,10 @@ RRT_DEV void enqueue_continuation(const DWork& wk, uint32_t bounce, bool cont, b
         // queue entry {o.xyz, d.xyz, (path, medium)}
         double* q = wk.q[(bounce + 1) & 1];
         const uint32_t slot = zero_mix ? (uint32_t)wk.cap - 1u - slot_dead : slot_live;
-        const uint32_t off = slot * (uint32_t)(kRecDoubles * 8);
-        at_off<f64x2>(q, off) = f64x2{ro.x, ro.y};
-        at_off<f64x2>(q, off + 16u) = f64x2{ro.z, rd.x};
-        at_off<f64x2>(q, off + 32u) = f64x2{rd.y, rd.z};
-        at_off<uint2>(q, off + 48u) = make_uint2(path | (zero_mix ? kDeadSky : 0u), (uint32_t)medium);
+        at_rec<f64x2>(q, slot, 0u) = f64x2{ro.x, ro.y};
+        at_rec<f64x2>(q, slot, 16u) = f64x2{ro.z, rd.x};
+        at_rec<f64x2>(q, slot, 32u) = f64x2{rd.y, rd.z};
+        at_rec<uint2>(q, slot, 48u) = make_uint2(path | (zero_mix ? kDeadSky : 0u), (uint32_t)medium);
     }
 }
 
@@ -1297,11 +1317,12 @@ template <bool PRIMARY, int CULL, bool GROUPS, bool PL, class LDS>
 RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFrame& fr, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
                          uint32_t pixel, uint32_t sample, uint32_t tag_base, bool dead_sky = false,
-                         unsigned long long* tacc = nullptr, NextRay* next = nullptr, uint32_t cov = ~0u, uint64_t ebits = ~0ull) {
+                         unsigned long long* tacc = nullptr, NextRay* next = nullptr, uint32_t cov = ~0u, uint64_t ebits = ~0ull,
+                         uint32_t upath = 0u) {
+    // upath (primary kernel): the wave-uniform part of `path` (its chunk's first path), for the record addressing
     const uint64_t P = wk.cap;
     const uint32_t tag_off = path * 4u;
     (void)tag_base;
-    const uint32_t rec_off = path * (uint32_t)(kRecDoubles * 8);
     const bool aov = sample == 0u;
     bool cont = false, compact = false, zero_mix = false;
     V3 ro = mk(0., 0., 0.), rd = mk(0., 0., 0.);
@@ -1337,7 +1358,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
                     at_off<f64x2>(wk.samp, path * 24u) = f64x2{c0.x, c0.y};
                     at_off<double>(wk.samp, path * 24u + 16u) = c0.z;
                 }
-                st_rec(wk.rec + (size_t)bounce * kRecDoubles * P, rec_off, A, Pm, m.mixR);
+                st_rec<PRIMARY>(wk.rec + (size_t)bounce * kRecDoubles * P, upath, path - upath, A, Pm, m.mixR);
                 uint32_t kp = pixel, ks = sample;
                 if (!PRIMARY && m.lobe == 2) {
                     // the RNG stream of the diffuse lobe is keyed by the global pixel and sample of the path
@@ -1370,7 +1391,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             if (dead_sky && bounce == 1u) {
                 compact = true;          // the primary kernel already left this outcome in samp (see there)
             } else {
-            ld_rec(wk.rec + (size_t)k * kRecDoubles * P, rec_off, &A, &Pm, &mr);
+            ld_rec(wk.rec + (size_t)k * kRecDoubles * P, path, &A, &Pm, &mr);
             // dead_sky: the enclosing cast's mix() is +-0.0 (the queue entry says so), and a sky colour is
             // texel/255 >= +0, finite: its product with the mix is the same signed zero whatever the texel, so
             // the texel is not fetched.  The ray itself was cast like any other (reference ray semantics).
@@ -1386,7 +1407,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             for (uint32_t k = fold_from; k-- > 0;) {
                 double mr;
                 V3 A, Pm;
-                ld_rec(wk.rec + (size_t)k * kRecDoubles * P, rec_off, &A, &Pm, &mr);
+                ld_rec(wk.rec + (size_t)k * kRecDoubles * P, path, &A, &Pm, &mr);
                 col = (A + col * mr) + Pm;
             }
             if (!(RRT_ABL & 16) || col.x == 12345.678) {
@@ -1563,7 +1584,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
             primary_ray(fr, lds, x, y, sample, &o, &d);
         }
         process_ray<true, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample, tag_base,
-                                            false, nullptr, nullptr, cov, ebits);
+                                            false, nullptr, nullptr, cov, ebits, chunk * 256u);
     }
 }
 
@@ -1609,17 +1630,17 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
         // unit -> queue entries: live units count up from entry 0, dead units down from entry P - 1
         const uint32_t unit = u * gridDim.x + blockIdx.x;
         const bool live_unit = unit < live_units;
-        const uint32_t k = (live_unit ? unit : unit - live_units) * 64u + lane;
+        const uint32_t kk = (live_unit ? unit : unit - live_units) * 64u, k = kk + lane;
         const bool active = k < (live_unit ? n_live : n_dead);
-        const uint32_t i = live_unit ? k : (uint32_t)P - 1u - k;
+        // entry ub + li: ub wave-uniform (P is a multiple of 256, so a dead unit's 64 entries are one aligned group too)
+        const uint32_t ub = live_unit ? kk : (uint32_t)P - 64u - kk, li = live_unit ? lane : 63u - lane;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         uint32_t path = 0;
         bool dead_sky = false;
         int32_t medium = -1;
         if (active) {
-            const uint32_t off = i * (uint32_t)(kRecDoubles * 8);
-            const f64x2 a = at_off<f64x2>(q, off), b = at_off<f64x2>(q, off + 16u), c = at_off<f64x2>(q, off + 32u);
-            const uint2 pm = at_off<uint2>(q, off + 48u);
+            const f64x2 a = at_rec<f64x2>(q, ub, li, 0u), b = at_rec<f64x2>(q, ub, li, 16u), c = at_rec<f64x2>(q, ub, li, 32u);
+            const uint2 pm = at_rec<uint2>(q, ub, li, 48u);
             o = mk(a.x, a.y, b.x);
             d = mk(b.y, c.x, c.y);
             path = pm.x & ~kDeadSky;
