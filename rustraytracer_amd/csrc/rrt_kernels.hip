@@ -2124,7 +2124,8 @@ void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t
     // 259 k chunks: 16384 blocks 57.0 ms, 32768 56.5), a multiple of 8
     // for the XCD-aware order, at least 2048 blocks so that a small launch still fills the chip
     const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
-    uint64_t want = (chunks / 8 + 2047) / 2048 * 2048;      // in steps of 2048 blocks = two rounds of resident blocks
+    static const uint64_t per_block = [] { const char* e = getenv("RRT_CHUNKS_PER_BLOCK"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 8); }();
+    uint64_t want = (chunks / per_block + 2047) / 2048 * 2048;      // in steps of 2048 blocks = two rounds of resident blocks
     if (want > chunks) want = chunks;
     if (want > trace_grid()) want = trace_grid();
     if (want >= 8) want -= want % 8;
