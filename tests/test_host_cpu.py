@@ -106,6 +106,13 @@ def test_scene_argument_errors(H):
         w.tree(0)
     with pytest.raises(B.RrtError, match="bad face"):
         B.check(B.lib.rrt_set_sky_face(w.h, 7, np.zeros(3, np.uint8).ctypes.data, 1, 1))
+    # rrt_cover_mask checks its arguments before it touches the device (no GPU here)
+    with pytest.raises(B.RrtError, match="not a mesh"):
+        w.cover_mask(0, 64, 32)
+    with pytest.raises(B.RrtError, match="not a mesh"):
+        w.cover_mask(5, 64, 32)
+    with pytest.raises(B.RrtError, match="empty image"):
+        w.cover_mask(0, 0, 32)
     assert H.tile_slots(1920, 1080, 1) == 60 * 135
     assert H.tile_slots(1920, 1080, 8) == (60 * 135 + 7) // 8
     assert H.tile_slots(33, 9, 2) == 2
