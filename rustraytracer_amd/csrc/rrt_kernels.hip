@@ -838,6 +838,7 @@ RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, 
                 else G = sc.groups[ent.index];
                 Closest h;
                 group_collide<CULL, false>(sc, lds, G, lnodes, o, d, medium, &h, stats, 0.0, cov, ebits);
+                if (CULL == 2 && binned && h.ent >= 0) atomicAdd(&stats[2], 1ull);    // a group is binned when all its members are
                 if (h.ent >= 0 && h.dist < best->dist) *best = h;
                 continue;
             }
@@ -1975,6 +1976,15 @@ __global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint
         }
         if (!may) bits &= ~(1ull << e);
     }
+    // a Scene<T> answers only through a member (scene.rs:50-52 = the kd walk over its members): no member that can be
+    // met, no group.  (Members of any group count: with several groups that only keeps a bit too many.)
+    uint64_t members = 0ull, groups = 0ull;
+    for (int32_t e = 0; e < sc.n_ents && e < 64; ++e) {
+        const int32_t k = sc.ents[e].kind;
+        if (k & kEntityMember) members |= 1ull << e;
+        else if (k == 2) groups |= 1ull << e;
+    }
+    if ((bits & members) == 0ull && sc.n_ents <= 64) bits &= ~groups;
     bins[tile] = bits;
 }
 
