@@ -456,6 +456,10 @@ RRT_DEV void mesh_collide(const DMesh& M, const CullConst& K, const DNodeI* lnod
     } else {
         lr = find_point(M.nodes, M.boxes, lnodes, 0, point);
     }
+    // (a ray that starts inside the root box is handed its EXIT point by aabb.rs:56-72, and that point + 0.01 d lies
+    // outside the box: kdtree.rs:23-24 answers None -- every reflection ray off the mesh itself ends here, before the
+    // cull constants are formed)
+    if (lr.leaf < 0) return;
     CullRay cr;
     if (CULL != 0) cr = make_cull_ray(K, o, d, inv);
     const RRT_GLOBAL DLeaf* leaves = as_global(M.leaves);
