@@ -1584,6 +1584,21 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         // spare the two SGPRs, it measured slower: cfg2 primary kernel 1.00 against 0.96 ms)
         uint64_t ebits = ~0ull;
         if (CULL != 0 && fr.tile_bins && tile < fr.tiles_x * fr.tiles_y) ebits = fr.tile_bins[ty * fr.tiles_x + tx];   // scalar load
+        if (CULL == 1 && ebits == 0ull) {
+            // No entity can be met anywhere in this tile (four tiles of five on the UFO frame): every ray of the chunk
+            // ends in the sky.  Wave-uniform, so this is the whole iteration -- the same ray, the same texel, the same
+            // sample word as process_ray's miss arm, without the hit path's registers around it.
+            if (active) {
+                primary_ray(fr, lds, x, y, sample, &o, &d);
+                if (sample == 0u) {
+                    const size_t pixel = (size_t)y * fr.width + x;
+                    if (d_ids) { d_ids[2 * pixel] = -1; d_ids[2 * pixel + 1] = -1; }
+                    if (d_t) d_t[pixel] = 0.0;
+                }
+                at_off<uint32_t>(wk.samp32, path * 4u) = kSampTexel | sky_texel(sc, lds, d);
+            }
+            continue;
+        }
         if (active) {
             if (CULL != 0) cov = cover_bits(lds, x, y);       // requested before the ray is generated
             primary_ray(fr, lds, x, y, sample, &o, &d);
@@ -1989,6 +2004,7 @@ __global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint
         else if (k == 2) groups |= 1ull << e;
     }
     if ((bits & members) == 0ull && sc.n_ents <= 64) bits &= ~groups;
+    if (sc.n_ents < 64) bits &= (1ull << sc.n_ents) - 1ull;      // no entity, no bit: 0 = "only sky behind this tile"
     bins[tile] = bits;
 }
 
