@@ -2149,12 +2149,15 @@ inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) 
     }()
 
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
-    // about eight 256-path chunks per persistent block (the per-block LDS staging is then ~3 % of its work; measured
+    // about sixteen 256-path chunks per persistent block (eight until the sky-only arm made most chunks cheap: with three
+    // frames in flight 16 chunks a block give 36.1 Grays/s on the UFO frame, 8: 35.4, 32: 35.3; one frame at a time 8 is
+    // 2 % ahead)
+    // earlier sweep, at eight: about eight 256-path chunks per persistent block (the per-block LDS staging is then ~3 % of its work; measured
     // on the full cfg2 frame, 130 k chunks: 4096 blocks 1.63 ms, 8192 1.51, 16384 1.47, 32768 1.51; on the height field's
     // 259 k chunks: 16384 blocks 57.0 ms, 32768 56.5), a multiple of 8
     // for the XCD-aware order, at least 2048 blocks so that a small launch still fills the chip
     const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
-    static const uint64_t per_block = [] { const char* e = getenv("RRT_CHUNKS_PER_BLOCK"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 8); }();
+    static const uint64_t per_block = [] { const char* e = getenv("RRT_CHUNKS_PER_BLOCK"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 16); }();
     uint64_t want = (chunks / per_block + 2047) / 2048 * 2048;      // in steps of 2048 blocks = two rounds of resident blocks
     if (want > chunks) want = chunks;
     if (want > trace_grid()) want = trace_grid();
