@@ -2149,13 +2149,12 @@ inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) 
     }()
 
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
-    // about sixteen 256-path chunks per persistent block (eight until the sky-only arm made most chunks cheap: with three
-    // frames in flight 16 chunks a block give 36.1 Grays/s on the UFO frame, 8: 35.4, 32: 35.3; one frame at a time 8 is
-    // 2 % ahead)
-    // earlier sweep, at eight: about eight 256-path chunks per persistent block (the per-block LDS staging is then ~3 % of its work; measured
-    // on the full cfg2 frame, 130 k chunks: 4096 blocks 1.63 ms, 8192 1.51, 16384 1.47, 32768 1.51; on the height field's
-    // 259 k chunks: 16384 blocks 57.0 ms, 32768 56.5), a multiple of 8
-    // for the XCD-aware order, at least 2048 blocks so that a small launch still fills the chip
+    // About sixteen 256-path chunks per persistent block, in a grid that is a multiple of 8 (the XCD-aware order) and of
+    // at least 2048 blocks (a small launch still fills the chip).  Sweeps on the full cfg2 frame (130 k chunks), one
+    // frame at a time, before the sky-only arm: 4096 blocks 1.63 ms, 8192 1.51, 16384 1.47, 32768 1.51.  With that arm
+    // most chunks are cheap and the per-block LDS staging weighs more: three frames in flight, 16 chunks a block give
+    // 36.1 Grays/s, 8: 35.4, 32: 35.3 (one frame at a time 8 is 2 % ahead).  Height field, 259 k chunks a launch: 16384
+    // blocks 57.0 ms, 32768 56.5.
     const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
     static const uint64_t per_block = [] { const char* e = getenv("RRT_CHUNKS_PER_BLOCK"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 16); }();
     uint64_t want = (chunks / per_block + 2047) / 2048 * 2048;      // in steps of 2048 blocks = two rounds of resident blocks
