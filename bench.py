@@ -390,10 +390,18 @@ def main():
             return median(ts[1:])
         scene.set_timing(0)      # as the N-rank path runs it
         t_full = frame_ms(0, 1, frames)
+        torch.cuda.synchronize()
+        full_stats = scene.stats()
+        full_rays = int(full_stats["rays_traced"])
         locals_ = [D.alloc_tile_buffers(w, h, 8, dev)[0] for _ in range(depth)]
         t_rank = [frame_ms(r, 8, locals_) for r in range(8)]
         rank_share = {"tile_world": 8, "spp_total": STRONG_SPP, "frames_in_flight": depth, "t_full_ms": t_full, "t_rank_ms": t_rank,
                       "rank_share_efficiency": (t_full / 8.0) / max(t_rank),
+                      # the strong-scaling frame on ONE GPU: the denominator for `--gpus N` lines (their `value` is this
+                      # 64-spp frame; the N = 1 `value` above is the 16-spp frame of BASELINE configs[1], which packs
+                      # fewer samples a wave and is ~15 % slower per ray)
+                      "strong_frame_one_gpu": {"spp_total": STRONG_SPP, "ms_per_step": t_full, "rays_per_step": full_rays,
+                                               "value": full_rays / t_full / 1e3, "unit": "Mrays/s"},
                       "what": "T(full)/8 over max_r T(rank r of 8), each measured alone on this one GPU with the bench's frames in "
                               "flight, host-timed with a device sync around 12 frames; excludes the RCCL gather (0.78 MB per rank)"}
         # leave the work buffers sized for the bench frame again
