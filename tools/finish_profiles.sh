@@ -8,6 +8,21 @@ SFX=""
 if [ "$CFG" != "cfg2" ]; then SFX="_$CFG"; fi
 T=$TAG$SFX
 mkdir -p profiles/counters
+# gpurun merges every collection's raw files into the same local directories: keep only the newest file of each pass,
+# or the parsers below average this collection with the ones before it
+python3 - gpurun_out/sq_$T gpurun_out/pmc_$T gpurun_out/tcp_$T <<'PY'
+import glob, os, sys
+for top in sys.argv[1:]:
+    by_dir = {}
+    for f in glob.glob(top + "/**/*_counter_collection.csv", recursive=True):
+        by_dir.setdefault(os.path.dirname(f), []).append(f)
+    for d, fs in by_dir.items():
+        fs.sort(key=os.path.getmtime)
+        for f in fs[:-1]:
+            os.remove(f)
+            a = f.replace("_counter_collection.csv", "_agent_info.csv")
+            if os.path.exists(a): os.remove(a)
+PY
 cp gpurun_out/${T}_bench.json profiles/${T}_bench.json
 cp gpurun_out/${T}_kernel_stats.csv profiles/${T}_kernel_stats.csv
 cp gpurun_out/${T}_pmc_traffic.json profiles/pmc_traffic${SFX}.json
