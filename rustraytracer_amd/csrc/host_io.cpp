@@ -231,6 +231,10 @@ int load_png_rgb8(const char* path, std::vector<uint8_t>* rgb, uint32_t* w_out, 
         at += 12 + (size_t)len;
     }
     if (w == 0 || h == 0 || ctype < 0) return hfail(RRT_E_FORMAT, std::string(path) + ": missing IHDR");
+    // the PNG limit (2^31 - 1 per side) and the renderer's own (plan_frame: 2^31 - 1 pixels): beyond it the scanline
+    // and image sizes below (up to 8 bytes a pixel) could wrap size_t, and no frame or cubemap face is that large
+    if (w > 0x7fffffffu || h > 0x7fffffffu || (uint64_t)w * h > 0x7fffffffull)
+        return hfail(RRT_E_FORMAT, std::string(path) + ": image of " + std::to_string(w) + " x " + std::to_string(h) + " pixels is too large");
     if (interlace > 1) return hfail(RRT_E_FORMAT, std::string(path) + ": unknown interlace method");
     int channels;
     switch (ctype) {

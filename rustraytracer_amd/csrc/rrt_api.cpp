@@ -718,6 +718,8 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         if (cam && st && st->width && st->height && !s->dirty && s->cull_mode != 0 && cam->lens_z > 0.0 &&
             cam->lens_w > 0.0 && cam->lens_h > 0.0 && std::isfinite(cam->lens_z + cam->lens_w + cam->lens_h + cam->eye[0] + cam->eye[1] + cam->eye[2])) {
             n_cover = (uint32_t)s->cover.size();
+            // (a very tall, narrow image: the mask's byte count is a 32-bit field of DFrame -- no masks then)
+            if (cover_stride(st->width) * st->height + 8 > 0xffffffffull) n_cover = 0;
             mask_bytes = (uint64_t)n_cover * (cover_stride(st->width) * st->height + 8) + kCarveAlign;
             if (NOALLOC && mask_bytes > rrt::kScratchBytes / 8) { n_cover = 0; mask_bytes = 0; }     // a huge image: leave the scratch to the paths
             // bins are worth their launch once the frame has some paths (a 640x480 frame at 1 spp is four launches long)
@@ -737,7 +739,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     if (st->tile_world > 1 && (d_ids || d_t || d_color))
         return fail(RRT_E_INVALID, "AOV / f64 colour outputs need tile_world == 1");
     pl.fr.cover_stride = (uint32_t)cover_stride(st->width);
-    pl.fr.cover_bytes = pl.fr.cover_stride * st->height + 8;
+    pl.fr.cover_bytes = (uint32_t)std::min<uint64_t>(cover_stride(st->width) * st->height + 8, 0xffffffffull);   // n_cover is 0 when this saturates
     rrt::DWork wk{};
     hipStream_t stream = (hipStream_t)stream_v;
     WorkSet* ws = &s->noalloc_set;
@@ -1298,9 +1300,10 @@ static const rrt::KdTreeFlat* tree_of(const rrt_scene* s, int entity) {
     if (kind == 2) return &s->groups[(size_t)ent.index]->tree;
     return nullptr;
 }
-int rrt_cover_mask(rrt_scene* s, const rrt_camera* cam, uint32_t width, uint32_t height, int entity, uint8_t* pixels, int* every) {
+int rrt_cover_mask(rrt_scene* s, const rrt_camera* cam, uint32_t width, uint32_t height, int entity, uint8_t* pixels, int* every) try {
     if (!s || !cam || !pixels || !every || width == 0 || height == 0) return fail(RRT_E_INVALID, "null argument or empty image");
     if ((uint64_t)width * height > 0x7fffffffull) return fail(RRT_E_INVALID, "image too large");
+    if (cover_stride(width) * height + 8 > 0xffffffffull) return fail(RRT_E_INVALID, "image too tall for a coverage mask");
     if (entity < 0 || (size_t)entity >= s->ents.size() || (s->ents[(size_t)entity].kind & ~rrt::kEntityMember) != 1)
         return fail(RRT_E_INVALID, "entity is not a mesh");
     int rc = commit(s);
@@ -1330,6 +1333,8 @@ int rrt_cover_mask(rrt_scene* s, const rrt_camera* cam, uint32_t width, uint32_t
         for (uint32_t x = 0; x < width; ++x) pixels[(size_t)y * width + x] = cells[(size_t)y * fr.cover_stride + x / rrt::kCoverCell] ? 1 : 0;
     *every = cells[(size_t)fr.cover_bytes - 8] ? 1 : 0;
     return RRT_OK;
+} catch (...) {
+    return on_exception();
 }
 
 int rrt_mesh_tree_sizes(const rrt_scene* s, int entity, int32_t* n_nodes, int32_t* n_leaf_refs) {

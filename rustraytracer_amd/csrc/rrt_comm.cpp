@@ -6,6 +6,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -33,14 +34,20 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        // an RCCL this process already holds first (same SONAME: PyTorch's own copy), then the system's
-        const char* names[] = {"librccl.so.1", "librccl.so"};
-        for (const char* n : names)
-            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-        for (const char* n : names)
-            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        // an RCCL this process already holds first (same SONAME: PyTorch's own copy), then the system's.
+        // RRT_RCCL_LIB names the library instead (a host that ships its own RCCL; the test of the "not found" path).
+        const char* override_name = getenv("RRT_RCCL_LIB");
+        const char* defaults[] = {"librccl.so.1", "librccl.so"};
+        const char* one[] = {override_name};
+        const char* const* names = override_name ? one : defaults;
+        const int n_names = override_name ? 1 : 2;
+        for (int i = 0; i < n_names; ++i)
+            if (!r.lib) r.lib = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
+        for (int i = 0; i < n_names; ++i)
+            if (!r.lib) r.lib = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
         if (!r.lib) {
-            r.why = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+            const char* e = dlerror();      // ONE call: dlerror() clears the message it returns
+            r.why = std::string("RCCL not found: ") + (e ? e : "dlopen failed");
             return;
         }
         const auto sym = [&](const char* n) {
@@ -131,25 +138,30 @@ int rrt_gather_tiles(rrt_comm* c, const void* d_local, void* d_gathered, uint32_
         return RRT_OK;
     }
     // gather to one rank: every peer sends straight to the root -- xGMI is point to point, seven links end at the
-    // root, so the seven messages (0.78 MB each at 1080p on 8 GPUs) arrive side by side; no ring is needed
-    NCCL_TRY(R->GroupStart());
+    // root, so the seven messages (0.78 MB each at 1080p on 8 GPUs) arrive side by side; no ring is needed.
+    // The root's own share is a plain copy, issued before the group opens.
     if (c->rank == root) {
-        for (int r = 0; r < c->world; ++r) {
-            char* dst = (char*)d_gathered + (size_t)r * bytes;
-            if (r == root) {
-                const hipError_t e = hipMemcpyAsync(dst, d_local, bytes, hipMemcpyDeviceToDevice, stream);
-                if (e != hipSuccess) {
-                    (void)R->GroupEnd();
-                    return cfail(RRT_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
-                }
-            } else {
-                NCCL_TRY(R->Recv(dst, bytes, ncclUint8, r, c->comm, stream));
-            }
+        const hipError_t e = hipMemcpyAsync((char*)d_gathered + (size_t)root * bytes, d_local, bytes, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return cfail(RRT_E_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    }
+    NCCL_TRY(R->GroupStart());
+    // Every exit from here on closes the group: a group left open queues every later collective of this thread and
+    // never issues it (a hang).  The first error is kept, the remaining calls are skipped, GroupEnd always runs.
+    ncclResult_t first = ncclSuccess;
+    const char* where = "";
+    if (c->rank == root) {
+        for (int r = 0; r < c->world && first == ncclSuccess; ++r) {
+            if (r == root) continue;
+            first = R->Recv((char*)d_gathered + (size_t)r * bytes, bytes, ncclUint8, r, c->comm, stream);
+            where = "ncclRecv";
         }
     } else {
-        NCCL_TRY(R->Send(d_local, bytes, ncclUint8, root, c->comm, stream));
+        first = R->Send(d_local, bytes, ncclUint8, root, c->comm, stream);
+        where = "ncclSend";
     }
-    NCCL_TRY(R->GroupEnd());
+    const ncclResult_t end = R->GroupEnd();
+    if (first != ncclSuccess) return cfail(RRT_E_HIP, std::string(where) + ": " + R->GetErrorString(first));
+    if (end != ncclSuccess) return cfail(RRT_E_HIP, std::string("ncclGroupEnd: ") + R->GetErrorString(end));
     return RRT_OK;
 }
 

@@ -313,3 +313,44 @@ def test_obj_triangulation_loads_the_reference_ufo(H, O, scenes, tmp_path):
     assert pv.shape == (3, 3, 3)
     assert np.array_equal(pv[:, 0, :2], [[0, 0]] * 3) and np.array_equal(pv[:, 1, :2], [[2, 0], [3, 1], [1, 3]]) \
         and np.array_equal(pv[:, 2, :2], [[3, 1], [1, 3], [-1, 1]])
+
+
+def test_absent_rccl_is_a_status_code_not_a_crash():
+    """A host without librccl: rrt_comm_unique_id / rrt_comm_init answer RRT_E_STATE with a message (the loader's
+    dlerror() text is read ONCE -- a second call returns NULL).  RRT_RCCL_LIB points the loader at a library that
+    does not exist; a process of its own, because the library is resolved once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, os\n"
+        "os.environ['RRT_NO_TORCH'] = '1'\n"
+        "from rustraytracer_amd import binding as B\n"
+        "buf = (C.c_ubyte * 128)()\n"
+        "rc = B.lib.rrt_comm_unique_id(buf)\n"
+        "msg = B.lib.rrt_last_error().decode()\n"
+        "assert rc == -3 and 'RCCL not found' in msg and 'no_such_rccl' in msg, (rc, msg)\n"
+        "out = C.c_void_p()\n"
+        "rc = B.lib.rrt_comm_init(0, 1, buf, C.byref(out))\n"
+        "assert rc == -3 and not out.value, rc\n"
+        "assert B.lib.rrt_gather_tiles(None, None, None, 64, 64, 0, None) == -1\n"
+        "print('ok')\n")
+    env = dict(os.environ, RRT_RCCL_LIB="/nonexistent/libno_such_rccl.so", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_png_with_an_oversized_header_is_refused(H, tmp_path):
+    """IHDR sizes near 2^31 / 2^32 would wrap the scanline and image byte counts: refused right after the header
+    (RRT_E_FORMAT), before anything is allocated."""
+    import struct
+    import zlib
+    from rustraytracer_amd import binding as B
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    for w, h in ((0xfffffff0, 0xfffffff0), (0x80000001, 1), (70000, 70000)):
+        p = tmp_path / ("big_%x_%x.png" % (w, h))
+        p.write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 6, 0, 0, 0))
+                      + chunk(b"IDAT", zlib.compress(b"\0")) + chunk(b"IEND", b""))
+        with pytest.raises(B.RrtError, match="too large"):
+            H.loaders.load_png(str(p))

@@ -2,12 +2,14 @@
 # per-launch start/duration of the last frames of tools/rank_frame.py:  bash tools/ktrace_rank.sh "<rank> <frames> [world]" [ENV=...]
 set -e
 ARGS=${1:-"7 6"}
+TAG=${TAG:-ktr}
+export TAG
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ktr -- python3 $GRAFT_REPO_ROOT/tools/rank_frame.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/ktr.log 2>&1
+timeout -s KILL 200 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/$TAG -- python3 $GRAFT_REPO_ROOT/tools/rank_frame.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
-import csv, glob
-f = sorted(glob.glob("gpurun_out/ktr/**/*kernel_trace.csv", recursive=True))[-1]
+import csv, glob, os
+f = sorted(glob.glob("gpurun_out/%s/**/*kernel_trace.csv" % os.environ["TAG"], recursive=True), key=os.path.getmtime)[-1]
 rows = [x for x in csv.DictReader(open(f)) if any(k in x["Kernel_Name"] for k in ("k_wave", "k_accum", "k_cover", "k_bins", "fillBuffer"))]
 rows.sort(key=lambda x: int(x["Start_Timestamp"]))
 last = rows[-18:]
