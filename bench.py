@@ -8,11 +8,13 @@ shading -> reflection bounces -> sky lookup -> accumulate -> quantise, and for
 N > 1 the framebuffer gather over RCCL + de-interleave) over one frame.  The
 scene is resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-N = 1 (the contract's bench line): BASELINE.json configs[1] -- the main.rs world
-(ufo_fix.obj kd-tree + 2 spheres) under the blue_sunset cubemap at 1920x1080,
-16 spp.  `--config cfg5` runs configs[4] (2M-triangle mesh, the HBM-bound
-config) with its own roofline and cpu_baseline; the other configs print the
-same line without them.
+N = 1 (the contract's bench line): the frame BASELINE.json's metric and north_star's
+target are quoted on -- the main.rs world (ufo_fix.obj kd-tree + 2 spheres) under the
+blue_sunset cubemap at 1920x1080, 64 spp -- THE SAME FRAME every `--gpus N` line
+renders, so value(N) / value(1) is a true strong-scaling ratio.  BASELINE configs[1]'s
+own sampling (16 spp) is measured in the same run and rides along as `configs1_16spp`.
+`--config cfg5` runs configs[4] (2M-triangle mesh) with its own roofline and
+cpu_baseline; the other configs print the same line without them.
 
 N > 1: without WORLD_SIZE in the environment the script starts its N ranks
 itself (a child `python -m torch.distributed.run`, before anything touches the
@@ -135,7 +137,8 @@ def cpu_leg(config, n_threads, w, h, spp, max_bounce):
     probe = cpu.render(w, h, spp=1, max_bounce=max_bounce, n_threads=n_threads, y0=5, row_stride=54, want=())   # 20 rows
     rate = int(probe["counters"][0]) / (time.perf_counter() - t0)        # rays/s, rough
     rays_frame = int(probe["counters"][0]) / 20.0 * h * spp
-    stride = 1 if config == "cfg2" else max(1, int(rays_frame / (rate * 3.0)))
+    # cfg2: every (spp/16)-th row of the frame = the rays of one 16-spp frame; else ~3 s of work
+    stride = max(1, spp // 16) if config == "cfg2" else max(1, int(rays_frame / (rate * 3.0)))
     dt, frames, c = 0.0, 0, None
     while dt < 2.0 and frames < 16:
         t0 = time.perf_counter()
@@ -155,14 +158,15 @@ def cpu_leg(config, n_threads, w, h, spp, max_bounce):
         # the reference's own work split (SURVEY 8d "faithful" mode): 12 threads over 12 contiguous row-major
         # chunks of W*H/12 pixels (tracer.rs:117-158) -- the slowest chunk sets the time
         L.orc_set_static_chunks(1)
+        spp_f = min(spp, 16)             # bounded: a quarter of the 64 samples (the split, not the sampling, is the point)
         t0 = time.perf_counter()
-        outf = cpu.render(w, h, spp=spp, seed=0, n_threads=12, want=())
+        outf = cpu.render(w, h, spp=spp_f, seed=0, n_threads=12, want=())
         dtf = time.perf_counter() - t0
         L.orc_set_static_chunks(0)
         base["reference_work_split"] = {
             "value": int(outf["counters"][0]) / dtf / 1e6, "unit": "Mrays/s", "threads": 12,
             "sample": "one full %dx%d frame at %d spp in 12 static contiguous pixel chunks as tracer.rs:117-158: "
-                      "%d rays in %.2f s" % (w, h, spp, int(outf["counters"][0]), dtf)}
+                      "%d rays in %.2f s" % (w, h, spp_f, int(outf["counters"][0]), dtf)}
     # per-primary-ray traversal work: closest hit of the sample-0 primary rays of every 32nd row
     st = O.Settings(w, h, 1, max_bounce, 0, 0, 1)
     cam = O.default_camera()
@@ -228,6 +232,12 @@ def attach_profiles(roof, config):
                                     "issue_slot_frac": v["valu_busy"] * (v["lane_utilisation"] or 0.0),
                                     "waves_per_simd": v["waves_per_simd"], "avg_launch_ns": v["avg_launch_ns"],
                                     "source": "profiles/valu_busy%s.json: %s" % (sfx, v.get("source"))}
+                # what the kernel EXECUTES, beside the delivered-work `frac`: the time its VALU wave-instructions
+                # need at one issue per SIMD every 4 cycles, against the launch they were counted in
+                if v.get("valu_wave_insts"):
+                    roof["issue_floor_ms"] = v["valu_wave_insts"] * 4.0 / (1024 * 2.4e9) * 1e3
+                    roof["launch_ms"] = v["avg_launch_ns"] * 1e-6
+                    roof["issue_floor_frac"] = roof["issue_floor_ms"] / roof["launch_ms"]
         except (ValueError, KeyError):
             pass
     return traffic
@@ -261,8 +271,12 @@ def main():
 
     from rustraytracer_amd import host as Hst, scenes, distributed as D
     scene_fn, w, h, spp0, max_bounce, what = CONFIGS[args.config]
+    side16_spp = 0
     if args.spp > 0:
         spp0 = args.spp
+    elif args.config == "cfg2":
+        # the bench frame = north_star's target (1080p, 64 spp), the same at every N; configs[1]'s 16 spp rides along
+        side16_spp, spp0 = spp0, STRONG_SPP
     scene = getattr(scenes, scene_fn)(Hst.World(device=local_rank), Hst.loaders)
     if args.budget_gib > 0:
         scene.set_work_budget(int(args.budget_gib * (1 << 30)))
@@ -334,7 +348,20 @@ def main():
 
     other = None
     sequential = None
+    side16 = None
     if world == 1:
+        if side16_spp and not args.once:
+            # BASELINE configs[1] as written (16 spp): in flight and one frame at a time, with its kernel times
+            f16, _ = figure(side16_spp)
+            scene.set_timing(2)
+            s16, st16 = figure(side16_spp, 1)
+            scene.set_timing(0)
+            side16 = {"what": "BASELINE configs[1] at its own sampling: the same scene and frame at %d spp" % side16_spp,
+                      "value": f16["value"], "unit": "Mrays/s", "ms_per_step": f16["ms_per_step"], "spp_total": side16_spp,
+                      "rays_per_step": f16["rays_per_step"], "timing": f16["timing"],
+                      "one_frame_at_a_time": {"value": s16["value"], "ms_per_step": s16["ms_per_step"]},
+                      "kernel_ms": {"k_wave_primary": st16["primary_kernel_ms"], "k_wave_bounce": st16["bounce_kernel_ms"],
+                                    "gpu": st16["gpu_ms"]}}
         main_fig, stats = figure(spp0)
         scaling = "strong"                    # one GPU: the distinction is empty; N > 1 defaults to strong
         if depth > 1:
@@ -342,7 +369,7 @@ def main():
             sequential, stats = figure(spp0, 1)
             scene.set_timing(0)
     else:
-        spp_strong, spp_weak = (STRONG_SPP if args.config == "cfg2" and not args.spp else spp0), spp0 * world
+        spp_strong, spp_weak = spp0, (side16_spp or spp0) * world
         strong, stats_s = figure(spp_strong)
         weak, stats_w = figure(spp_weak)
         scaling = args.scaling
@@ -397,9 +424,7 @@ def main():
         t_rank = [frame_ms(r, 8, locals_) for r in range(8)]
         rank_share = {"tile_world": 8, "spp_total": STRONG_SPP, "frames_in_flight": depth, "t_full_ms": t_full, "t_rank_ms": t_rank,
                       "rank_share_efficiency": (t_full / 8.0) / max(t_rank),
-                      # the strong-scaling frame on ONE GPU: the denominator for `--gpus N` lines (their `value` is this
-                      # 64-spp frame; the N = 1 `value` above is the 16-spp frame of BASELINE configs[1], which packs
-                      # fewer samples a wave and is ~15 % slower per ray)
+                      # the same frame as `value` above, re-timed here next to the rank frames (host clock, 12 frames)
                       "strong_frame_one_gpu": {"spp_total": STRONG_SPP, "ms_per_step": t_full, "rays_per_step": full_rays,
                                                "value": full_rays / t_full / 1e3, "unit": "Mrays/s"},
                       "what": "T(full)/8 over max_r T(rank r of 8), each measured alone on this one GPU with the bench's frames in "
@@ -426,9 +451,8 @@ def main():
             "timing": main_fig["timing"],
             "config": {"workload": ("BASELINE configs[1]: main.rs world (ufo_fix.obj rope kd-tree, 1705 tris, + 2 spheres), "
                                     "blue_sunset cubemap, %dx%d, %d spp in total%s, max_bounce 2, reference ray semantics "
-                                    "(prune_zero_mix=%d)" % (w, h, spp, "" if world == 1 else
-                                                             (" (north_star's target frame, fixed as N grows)" if scaling == "strong"
-                                                              else " (16 per GPU)"), args.prune))
+                                    "(prune_zero_mix=%d)" % (w, h, spp, (" (north_star's target frame, the same at every N)" if spp == STRONG_SPP and not args.spp else "")
+                                                             if world == 1 or scaling == "strong" else " (16 per GPU)", args.prune))
                        if cfg2 else "BASELINE %s; %d spp in total, max_bounce %d" % (what, spp, max_bounce),
                        "rays_per_step": main_fig["rays_per_step"], "samples_per_step": main_fig["samples_per_step"],
                        "msamples_per_s": main_fig["samples_per_step"] / main_fig["ms_per_step"] / 1e3,
@@ -446,6 +470,8 @@ def main():
                 "rays_per_step": other["rays_per_step"], "timing": other["timing"]}
         if host_ms is not None:
             line["config"]["host_buffer_ms_per_step"] = host_ms      # rrt_render: + D2H of the RGB8 frame, blocking
+        if side16 is not None:
+            line["configs1_16spp"] = side16
         if rank_share is not None:
             line["rank_share_efficiency"] = rank_share["rank_share_efficiency"]
             line["rank_share"] = rank_share

@@ -83,9 +83,15 @@ extern "C" {
     pub fn rrt_add_sphere(s: *mut rrt_scene, center: *const f64, radius: f64, material: c_int) -> c_int;
     pub fn rrt_add_mesh(s: *mut rrt_scene, verts: *const f64, normals: *const f64, n_triangles: i64,
                         material: c_int) -> c_int;
+    /// Triangle::new + push: a bare triangle as an entity of its own (triangle.rs:19-58), no kd-tree around it.
+    pub fn rrt_add_triangle(s: *mut rrt_scene, v0: *const f64, v1: *const f64, v2: *const f64, normal: *const f64,
+                            material: c_int) -> c_int;
     pub fn rrt_add_group(s: *mut rrt_scene, members: *const i32, n_members: i32) -> c_int;
     pub fn rrt_set_sky_face(s: *mut rrt_scene, face: c_int, rgb8: *const u8, w: u32, h: u32) -> c_int;
     pub fn rrt_set_directional_light(s: *mut rrt_scene, direction: *const f64, color: *const f64,
+                                     intensity: f64) -> c_int;
+    /// DirectionalLight::new + world.light_sources.push: appends (the set_ variant makes the list [this light]).
+    pub fn rrt_add_directional_light(s: *mut rrt_scene, direction: *const f64, color: *const f64,
                                      intensity: f64) -> c_int;
     pub fn rrt_add_point_light(s: *mut rrt_scene, position: *const f64, color: *const f64, brightness: f64,
                                attenuation: f64) -> c_int;
@@ -111,6 +117,11 @@ extern "C" {
                                      d_rgb8: *mut c_void, d_ids: *mut c_void, d_t: *mut c_void, d_color: *mut c_void,
                                      stream: *mut c_void) -> c_int;
     pub fn rrt_noalloc_scratch_bytes() -> u64;
+    /// Page-locked host memory: rrt_render fills such a destination band by band while the frame is being resolved.
+    pub fn rrt_alloc_host_pinned(bytes: u64) -> *mut c_void;
+    pub fn rrt_free_host_pinned(p: *mut c_void);
+    /// Gives back the work buffers the scene keeps for `stream` (call before destroying a stream it rendered on).
+    pub fn rrt_release_stream(s: *mut rrt_scene, stream: *mut c_void) -> c_int;
     pub fn rrt_tile_skew(width: u32, tile_world: u32) -> u32;
     pub fn rrt_comm_unique_id(id128: *mut c_void) -> c_int;
     pub fn rrt_comm_init(rank: c_int, world: c_int, id128: *const c_void, out: *mut *mut rrt_comm) -> c_int;

@@ -10,8 +10,8 @@
  * is one blocking call into this library.  Because `dyn` traits are open sets
  * and a GPU needs closed ones, the ABI is a scene-description API over the
  * closed set the reference ships: entity kinds {sphere, triangle mesh + rope
- * kd-tree}, behaviour kinds {lambert, reflection, phong, cubemap}, light kinds
- * {directional}.  Each entry point cites the reference interface it replaces.
+ * kd-tree, bare triangle, Scene<T> group}, behaviour kinds {lambert, reflection,
+ * phong, cubemap}, light kinds {directional, point}.  Each entry point cites the reference interface it replaces.
  *
  * Conventions: plain pointers and sizes, no C++/torch types.  All functions
  * returning int return RRT_OK (0) or a negative RRT_E_* code; the message is
@@ -150,10 +150,20 @@ int rrt_add_sphere(rrt_scene* s, const double center[3], double radius, int mate
  * the tie order of its sort_unstable_by.  Returns the entity id. */
 int rrt_add_mesh(rrt_scene* s, const double* verts, const double* normals, int64_t n_triangles, int material);
 
+/* Triangle::new(v0, v1, v2, normal, material) + world.entities.push (src/geometry/triangle.rs:19-23 is `pub`, and
+ * Triangle implements Entity, triangle.rs:25-83): a bare triangle as an entity of its own.  Entity::collide is
+ * Triangle::collide (triangle.rs:25-58) and nothing else -- rrt_add_mesh with one triangle is NOT equivalent: that
+ * goes through Model's kd-tree, whose root-box test (aabb.rs:50-100 with the +0.001 nudge of :89) rejects every ray
+ * for an axis-aligned (flat-box) triangle.  `normal` is stored and returned as given (triangle.rs:54; not normalised,
+ * not derived from the vertices).  May also be a member of a group (rrt_add_group).  The id AOV reports the entity id
+ * and triangle id -1 ("not part of a mesh").  Returns the entity id. */
+int rrt_add_triangle(rrt_scene* s, const double v0[3], const double v1[3], const double v2[3], const double normal[3],
+                     int material);
+
 /* Scene::new(models, position) + world.entities.push(scene) (src/geometry/scene.rs:39-47; the
  * scene!/entity_enum! macros scene.rs:12-29 and #[derive(Entity)] derive_entity/src/lib.rs:7-51 are
  * the enum plumbing around it; usage commented out at src/main.rs:57-59).  `members` are ids of
- * spheres/meshes already added: they leave the world's entity list and are reached only through
+ * spheres / meshes / bare triangles already added: they leave the world's entity list and are reached only through
  * the group's kd-tree over their bounding boxes (KDTree<T>::new over entities, kdtree.rs:46-51),
  * whose collide (kdtree.rs:192-235) answers with the closest member of the first leaf in which
  * any member is hit -- after the tree's root box passed aabb.rs:50-100, so results can differ from
@@ -169,9 +179,15 @@ int rrt_add_group(rrt_scene* s, const int32_t* members, int32_t n_members);
  * [left,right,down,up,front,back] (cubemap.rs:47-48). rgb8: h rows of w texels. */
 int rrt_set_sky_face(rrt_scene* s, int face, const uint8_t* rgb8, uint32_t w, uint32_t h);
 
-/* DirectionalLight::new(direction, color, intensity) (src/lighting.rs:25-32;
- * direction is normalised inside, as there).  The reference world holds
- * exactly one (tracer.rs:55-65); a second call replaces it. */
+/* world.light_sources is a LIST (src/common.rs:12: Vec<Box<dyn LightSource>>): Lambert and Phong sum over it in
+ * push order (src/behavior/lambert.rs:34-43, phong.rs:37-45), and with f64 the order of a sum is part of the result.
+ * rrt_add_directional_light = DirectionalLight::new(direction, color, intensity) (src/lighting.rs:25-32; the
+ * direction is normalised inside, as there) + world.light_sources.push: appends, returns the light's index in the
+ * list.  rrt_add_point_light (below) appends to the SAME list, so directional and point lights interleave in the
+ * order the host pushes them.  At most 32 lights.
+ * rrt_set_directional_light = "the list becomes [this light]": what RayTracer::new_empty_world leaves behind
+ * (tracer.rs:55-65); lights pushed before it are dropped. */
+int rrt_add_directional_light(rrt_scene* s, const double direction[3], const double color[3], double intensity);
 int rrt_set_directional_light(rrt_scene* s, const double direction[3], const double color[3], double intensity);
 
 int rrt_set_ambient(rrt_scene* s, double ambient);             /* World.ambient, tracer.rs:73 */
@@ -180,11 +196,11 @@ int rrt_set_ambient(rrt_scene* s, double ambient);             /* World.ambient,
  * (src/lighting.rs:52-89).  The reference gives the struct no constructor and main.rs never builds
  * one (dead code there), so this is PARITY UNPINNED against the reference and
  * restated from the impl block alone: illuminate = {power: brightness / (attenuation * |pos-light|^2),
- * direction: normalize(pos - light)} (lighting.rs:60-68), summed by Lambert and Phong after the
- * directional light, in push order (lambert.rs:34-43, phong.rs:37-45).  At most 16.  Its visible()
+ * direction: normalize(pos - light)} (lighting.rs:60-68), summed by Lambert and Phong at its place in
+ * world.light_sources (push order across light kinds, lambert.rs:34-43, phong.rs:37-45).  At most 16.  Its visible()
  * casts a SHADOW RAY through the world -- an any-hit walk of the same entities / kd-trees (the
  * first accepted triangle that is close enough ends it) -- see rrt_set_shadow_mode.
- * Returns the light's index. */
+ * Returns the light's index in world.light_sources. */
 int rrt_add_point_light(rrt_scene* s, const double position[3], const double color[3], double brightness,
                         double attenuation);
 
@@ -237,9 +253,19 @@ int rrt_scene_commit(rrt_scene* s);
  *           hit; entity -1 = sky, triangle -1 = not a mesh            (may be NULL)
  * out_t     [H][W] f64 hit parameter t of that hit (0 for sky)        (may be NULL)
  * out_color [H][W][3] f64 un-quantised mean colour                    (may be NULL)
- * Requires tile_world == 1. */
+ * Requires tile_world == 1.  The frame runs on a stream of the scene's own and the call waits for that stream only
+ * (not for the device).  Destinations in page-locked memory (rrt_alloc_host_pinned) are filled band by band while
+ * the frame is still being resolved; pageable destinations by one copy after it. */
 int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint8_t* out_rgb8, int32_t* out_ids,
                double* out_t, double* out_color);
+
+/* Page-locked host memory for rrt_render's outputs (hipHostMalloc; no reference counterpart: the reference's image
+ * is a Vec inside `render`, src/tracer.rs:112).  rrt_render recognises ANY page-locked destination (these, a
+ * hipHostMalloc of the host's own, a hipHostRegister-ed range): its RGB8 frame is then resolved in four bands of tile
+ * rows, each copied into out_rgb8 by the copy engine while the next is resolved, instead of one staged copy of
+ * pageable memory after the frame (1080p: ~0.1 ms against ~0.4 ms on top of the kernels).  NULL on failure. */
+void* rrt_alloc_host_pinned(uint64_t bytes);
+void rrt_free_host_pinned(void* p);
 
 /* Same with DEVICE output pointers, asynchronous on `stream` (a hipStream_t,
  * NULL = default stream).  With tile_world > 1 d_rgb8 is this rank's compact
@@ -254,6 +280,13 @@ int rrt_render(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, uint
  * frames are in flight. */
 int rrt_render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, void* d_rgb8, void* d_ids,
                       void* d_t, void* d_color, void* stream);
+
+/* Gives back the work buffers the scene keeps for `stream` (see "frames in flight" above; no reference counterpart).
+ * A long-lived host that creates and destroys streams calls this before it destroys one: otherwise the scene keeps
+ * that stream's buffers (up to the work budget EACH) until rrt_scene_destroy, the ninth distinct stream is refused,
+ * and a recycled handle value would inherit the old set.  Waits for the stream's frames first.  RRT_E_INVALID if the
+ * scene has never rendered on that stream. */
+int rrt_release_stream(rrt_scene* s, void* stream);
 
 /* NO COUNTERPART IN THE REFERENCE.  For callers that cannot allocate: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments, outputs and

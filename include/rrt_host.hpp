@@ -53,19 +53,32 @@ struct Model {                                   // model.rs:24-56
     }
 };
 
+struct Triangle {                                // triangle.rs:19-23: an Entity of its own (no kd-tree around it)
+    Point3 v0, v1, v2; Vector3 normal; Material material;
+    static Triangle new_(Point3 v0, Point3 v1, Point3 v2, Vector3 normal, Material material) {
+        return Triangle{v0, v1, v2, normal, material};
+    }
+};
+
 // scene.rs:31-47 with the scene!/entity_enum! macros (scene.rs:12-29) and #[derive(Entity)]
 // (derive_entity/src/lib.rs) folded into one closed sum type: the enum those macros generate for
 // `entity_enum!(SceneType, Sphere, Model)` is exactly std::variant<Sphere, Model>, and the derived
 // `match self { V(a) => a.collide(ray) }` forwarding is what the kernels do on the entity kind.
 //     Scene::new_(Point3{0,0,0}, {Model(burger), Sphere(sphere), Sphere(sphere2)})   main.rs:57-58
 struct Scene {
-    using Member = std::variant<Sphere, Model>;
+    using Member = std::variant<Sphere, Model, Triangle>;
     std::vector<Member> models; Point3 position;
     static Scene new_(Point3 position, std::vector<Member> models) { return Scene{std::move(models), position}; }
 };
 
-// lighting.rs:52-68.  The reference never pushes one (World::light_sources holds DirectionalLights, common.rs:13);
-// here it goes behind the directional light, see rrt_add_point_light / rrt_set_shadow_mode.
+// lighting.rs:19-32
+struct DirectionalLight {
+    Vector3 direction, color; double intensity;
+    static DirectionalLight new_(Vector3 direction, Vector3 color, double intensity) { return DirectionalLight{direction, color, intensity}; }
+};
+
+// lighting.rs:52-68.  The reference never builds one (dead code); pushed to world.light_sources it is summed at its
+// place in the list, see rrt_add_point_light / rrt_set_shadow_mode.
 struct PointLight {
     Point3 position; Vector3 color; double brightness, radius;
     static PointLight new_(Point3 position, Vector3 color, double brightness, double radius) {
@@ -96,6 +109,14 @@ class World {
         check(id);
         return id;
     }
+    // world.entities.push(Box::new(triangle))   Triangle implements Entity (triangle.rs:25-83)
+    int push(const Triangle& t) {
+        const double a[3] = {t.v0.x, t.v0.y, t.v0.z}, b[3] = {t.v1.x, t.v1.y, t.v1.z}, c[3] = {t.v2.x, t.v2.y, t.v2.z},
+                     n[3] = {t.normal.x, t.normal.y, t.normal.z};
+        const int id = rrt_add_triangle(h_, a, b, c, n, material_id(t.material));
+        check(id);
+        return id;
+    }
     // world.entities.push(scene)                main.rs:59: the members are reachable through the
     // scene's kd-tree only (rrt_add_group); returns the scene's entity id
     int push(const Scene& sc) {
@@ -103,6 +124,13 @@ class World {
         for (const Scene::Member& m : sc.models)
             ids.push_back(std::visit([this](const auto& e) { return this->push(e); }, m));
         const int id = rrt_add_group(h_, ids.data(), (int32_t)ids.size());
+        check(id);
+        return id;
+    }
+    // world.light_sources.push(Box::new(light)) for a DirectionalLight (the list keeps push order, common.rs:12)
+    int push(const DirectionalLight& l) {
+        const double d[3] = {l.direction.x, l.direction.y, l.direction.z}, c[3] = {l.color.x, l.color.y, l.color.z};
+        const int id = rrt_add_directional_light(h_, d, c, l.intensity);
         check(id);
         return id;
     }

@@ -63,6 +63,8 @@ def lib():
         L.orc_add_group.restype = C.c_int
         L.orc_set_sky_face.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]
         L.orc_set_directional_light.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]
+        L.orc_add_directional_light.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double]
+        L.orc_add_triangle.argtypes = [C.c_void_p] + [C.POINTER(C.c_double)] * 4 + [C.c_int]
         L.orc_set_ambient.argtypes = [C.c_void_p, C.c_double]
         L.orc_add_point_light.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double]
         L.orc_set_shadow_mode.argtypes = [C.c_void_p, C.c_int]
@@ -210,6 +212,10 @@ class OracleScene:
         assert v.shape[0] == n.shape[0]
         return self.L.orc_add_mesh(self.h, _ptr(v), _ptr(n), v.shape[0], mat)
 
+    def add_triangle(self, v0, v1, v2, normal, mat):
+        """Triangle::new + push (triangle.rs:19-23): a bare triangle as an entity of its own."""
+        return self.L.orc_add_triangle(self.h, _d3(v0), _d3(v1), _d3(v2), _d3(normal), mat)
+
     def add_group(self, members):
         """Scene::new (scene.rs:39-47) over entities already added; returns the group's entity id."""
         m = np.ascontiguousarray(members, dtype=np.int32)
@@ -225,6 +231,13 @@ class OracleScene:
 
     def set_directional_light(self, direction, color, intensity):
         self.L.orc_set_directional_light(self.h, _d3(direction), _d3(color), float(intensity))
+
+    def add_directional_light(self, direction, color, intensity):
+        """DirectionalLight::new + world.light_sources.push (lighting.rs:25-32): appends."""
+        i = self.L.orc_add_directional_light(self.h, _d3(direction), _d3(color), float(intensity))
+        if i < 0:
+            raise ValueError("too many lights")
+        return i
 
     def set_ambient(self, a):
         self.L.orc_set_ambient(self.h, float(a))

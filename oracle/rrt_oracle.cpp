@@ -478,7 +478,8 @@ inline Collide sphere_collide_inside(const Sphere& s, const Ray& ray) {
     return r;
 }
 
-// kind 0 = sphere, 1 = mesh, 2 = group (Scene<T>, scene.rs:31-47); parent = the group an entity was
+// kind 0 = sphere, 1 = mesh, 2 = group (Scene<T>, scene.rs:31-47), 3 = a bare Triangle pushed as an entity of its
+// own (triangle.rs:19-58; `index` into Scene::tri_ents); parent = the group an entity was
 // moved into (then world.entities no longer lists it, main.rs:57-59), -1 = top level
 struct Entity { int kind; int index; int parent = -1; };
 
@@ -499,15 +500,16 @@ struct Scene {
     std::vector<std::unique_ptr<Group>> groups;
     std::vector<Entity> ents;
     Face sky[6];
-    // lighting.rs:25-32 (one DirectionalLight) ; tracer.rs:55-73
-    bool has_light = false;
-    V3 light_dir{0, 0, 0}, light_color{0, 0, 0}; double light_intensity = 0;
-    double ambient = 0.15;
-    // lighting.rs:52-57.  The reference gives PointLight no constructor (private fields, never built by
-    // main.rs): PARITY UNPINNED -- restated from the impl block alone.  world.light_sources order here:
-    // the directional light first (new_empty_world pushes it, tracer.rs:55-65), then these in push order.
-    struct PointLight { V3 pos, color; double brightness, attenuation; };
-    std::vector<PointLight> point_lights;
+    double ambient = 0.15;                                    // tracer.rs:73
+    // world.light_sources (common.rs:12): a Vec<Box<dyn LightSource>>, summed by Lambert and Phong in push order
+    // (lambert.rs:34-43, phong.rs:37-45).  kind 0 = DirectionalLight{direction (normalised), color, intensity}
+    // (lighting.rs:19-50; v = direction, a = intensity); kind 1 = PointLight{position, color, brightness,
+    // attenuation} (lighting.rs:52-89; v = position, a = brightness, b = attenuation).  The reference gives PointLight
+    // no constructor (private fields, never built by main.rs): PARITY UNPINNED -- restated from the impl block alone.
+    struct Light { int kind; V3 v, color; double a, b; };
+    std::vector<Light> lights;
+    struct TriEnt { Triangle tri; int mat; };
+    std::vector<TriEnt> tri_ents;
     int shadow_mode = 0;   // 0 = PointLight::visible exactly as written (lighting.rs:70-84); 1 = corrected (extension)
 };
 
@@ -548,8 +550,17 @@ inline V3 sky_color(const Scene& sc, V3 d) {
 
 struct Primary { int ent = -1; int tri = -1; double t = 0.0; };
 
-// Entity::collide of entity e (a sphere or a mesh).
+// Entity::collide of entity e (a sphere, a mesh or a bare triangle).
 inline Collide entity_collide(const Scene& sc, int e, const Ray& ray, Counters& c) {
+    if (sc.ents[e].kind == 3) {                       // Triangle::collide itself, triangle.rs:25-58
+        const Scene::TriEnt& T = sc.tri_ents[sc.ents[e].index];
+        Collide r;
+        ++c.tri_tests;
+        if (tri_collide(T.tri, ray.o, ray.d, &r.pos, &r.t)) {
+            r.hit = true; r.normal = T.tri.normal; r.mat = T.mat; r.tri = -1;
+        }
+        return r;
+    }
     if (sc.ents[e].kind == 0) {
         ++c.sphere_tests;
         return (e == ray.medium) ? sphere_collide_inside(sc.spheres[sc.ents[e].index], ray)
@@ -700,18 +711,18 @@ inline bool occluded(const Scene& sc, const Ray& ray, double lim2, Counters& c) 
 //  mode 1: EXTENSION, the corrected test: the surface must face the light (as DirectionalLight::visible,
 //          lighting.rs:43-45), the ray starts at pos + normal*0.3 (the offset reflection.rs:30 uses),
 //          is normalised, and the light is visible iff nothing is hit closer than the light.
-inline bool point_light_visible(const Scene& sc, const Scene::PointLight& L, V3 pos, V3 normal, Counters& c) {
+inline bool point_light_visible(const Scene& sc, const Scene::Light& L, V3 pos, V3 normal, Counters& c) {
     if (sc.shadow_mode == 0) {
-        Ray r; r.o = pos; r.d = sub(L.pos, pos); r.bounce = 0;
+        Ray r; r.o = pos; r.d = sub(L.v, pos); r.bounce = 0;
         for (size_t e = 0; e < sc.ents.size(); ++e) {
             if (sc.ents[e].parent >= 0) continue;
             if (!top_level_collide(sc, e, r, c).hit) return true;
         }
         return false;
     }
-    if (!(dot(normal, sub(pos, L.pos)) < 0.)) return false;
+    if (!(dot(normal, sub(pos, L.v)) < 0.)) return false;
     Ray r; r.o = add(pos, mul(normal, 0.3)); r.bounce = 0;
-    const V3 v = sub(L.pos, r.o);
+    const V3 v = sub(L.v, r.o);
     r.d = normalize(v);
     return !occluded(sc, r, mag2(v), c);
 }
@@ -725,27 +736,28 @@ V3 cast(const Scene& sc, const Settings& st, const Ray& ray, Counters& c, Primar
     if (hit.hit) {
         const Material& m = sc.mats[hit.mat];
         V3 final_color = mul(m.color, sc.ambient);
-        const bool visible = sc.has_light && (dot(hit.normal, sc.light_dir) < 0.);  // lighting.rs:43-45
-        // visible() of each point light: asked by Lambert and again by Phong (lambert.rs:35, phong.rs:38)
-        // with the same arguments, so evaluated once
-        bool pl_visible[16];
-        for (size_t k = 0; k < sc.point_lights.size(); ++k)
-            pl_visible[k] = point_light_visible(sc, sc.point_lights[k], hit.pos, hit.normal, c);
-        // shaders[0] = Lambert
+        // light_source.visible() and .illuminate() of every light of world.light_sources: asked by Lambert and again
+        // by Phong (lambert.rs:35-37, phong.rs:38-40) with the same arguments, so evaluated once per light
+        bool vis[32]; double pw[32]; V3 dirs[32];
+        for (size_t k = 0; k < sc.lights.size(); ++k) {
+            const Scene::Light& L = sc.lights[k];
+            if (L.kind == 0) {                                            // DirectionalLight, lighting.rs:35-45
+                vis[k] = dot(hit.normal, L.v) < 0.;
+                pw[k] = L.a; dirs[k] = L.v;
+            } else {                                                      // PointLight, lighting.rs:60-84
+                vis[k] = point_light_visible(sc, L, hit.pos, hit.normal, c);
+                const V3 dir0 = sub(hit.pos, L.v);
+                const double distance2 = mag2(dir0);
+                dirs[k] = normalize(dir0);
+                pw[k] = L.a / (L.b * distance2);
+            }
+        }
+        // shaders[0] = Lambert (lambert.rs:22-45): one sum over the lights in push order
         {
             V3 result{0., 0., 0.};
-            if (visible) {
-                double power = sc.light_intensity * (m.albedo / 3.14159265358979323846) * -dot(hit.normal, sc.light_dir);
-                power = std::fmax(power, 0.);
-                result = add(result, mul(m.color, power));
-            }
-            for (size_t k = 0; k < sc.point_lights.size(); ++k) {       // the other light_sources, lambert.rs:34-43
-                if (!pl_visible[k]) continue;
-                const Scene::PointLight& L = sc.point_lights[k];
-                const V3 dir0 = sub(hit.pos, L.pos);                      // lighting.rs:61-67
-                const double distance2 = mag2(dir0);
-                const V3 dir = normalize(dir0);
-                double power = (L.brightness / (L.attenuation * distance2)) * (m.albedo / 3.14159265358979323846) * -dot(hit.normal, dir);
+            for (size_t k = 0; k < sc.lights.size(); ++k) {
+                if (!vis[k]) continue;
+                double power = pw[k] * (m.albedo / 3.14159265358979323846) * -dot(hit.normal, dirs[k]);
                 power = std::fmax(power, 0.);
                 result = add(result, mul(m.color, power));
             }
@@ -760,20 +772,11 @@ V3 cast(const Scene& sc, const Settings& st, const Ray& ray, Counters& c, Primar
         // shaders[2] = Phong
         {
             V3 result{0., 0., 0.};
-            if (visible) {
-                const V3 bis = normalize(sub(neg(sc.light_dir), ray.d));
-                const double power = sc.light_intensity * powi(std::fmax(dot(bis, hit.normal), 0.), m.alpha);
-                result = add(result, mul(sc.light_color, power));
-            }
-            for (size_t k = 0; k < sc.point_lights.size(); ++k) {       // phong.rs:37-45
-                if (!pl_visible[k]) continue;
-                const Scene::PointLight& L = sc.point_lights[k];
-                const V3 dir0 = sub(hit.pos, L.pos);
-                const double distance2 = mag2(dir0);
-                const V3 dir = normalize(dir0);
-                const V3 bis = normalize(sub(neg(dir), ray.d));
-                const double power = (L.brightness / (L.attenuation * distance2)) * powi(std::fmax(dot(bis, hit.normal), 0.), m.alpha);
-                result = add(result, mul(L.color, power));
+            for (size_t k = 0; k < sc.lights.size(); ++k) {             // phong.rs:37-45
+                if (!vis[k]) continue;
+                const V3 bis = normalize(sub(neg(dirs[k]), ray.d));
+                const double power = pw[k] * powi(std::fmax(dot(bis, hit.normal), 0.), m.alpha);
+                result = add(result, mul(sc.lights[k].color, power));
             }
             final_color = add(final_color, mul(result, m.mixP));
         }
@@ -876,6 +879,8 @@ int orc_add_group(void* h, const int32_t* members, int n) {
         if (s->ents[e].kind == 0) {                       // sphere.rs:49-54
             const Sphere& sp = s->spheres[s->ents[e].index];
             b = AABB{{sp.c.x - sp.r, sp.c.y - sp.r, sp.c.z - sp.r}, {sp.c.x + sp.r, sp.c.y + sp.r, sp.c.z + sp.r}};
+        } else if (s->ents[e].kind == 3) {                // triangle.rs:60-65
+            b = s->tri_ents[s->ents[e].index].tri.bbox();
         } else {                                          // model.rs:68-70: the tree's root box
             b = s->meshes[s->ents[e].index]->root->box;
         }
@@ -902,21 +907,35 @@ void orc_set_sky_face(void* h, int face, const uint8_t* rgb, uint32_t w, uint32_
     s->sky[face].w = w; s->sky[face].h = hgt;
 }
 
-void orc_set_directional_light(void* h, const double dir[3], const double color[3], double intensity) {
+// DirectionalLight::new (lighting.rs:25-32) + world.light_sources.push; returns the light's index, -1 when full
+int orc_add_directional_light(void* h, const double dir[3], const double color[3], double intensity) {
     Scene* s = (Scene*)h;
-    s->has_light = true;
-    s->light_dir = normalize(V3{dir[0], dir[1], dir[2]});   // lighting.rs:26
-    s->light_color = V3{color[0], color[1], color[2]};
-    s->light_intensity = intensity;
+    if (s->lights.size() >= 32) return -1;
+    s->lights.push_back(Scene::Light{0, normalize(V3{dir[0], dir[1], dir[2]}) /* lighting.rs:26 */, V3{color[0], color[1], color[2]}, intensity, 0.0});
+    return (int)s->lights.size() - 1;
+}
+// world.light_sources = [this light]: what new_empty_world leaves (tracer.rs:55-65)
+void orc_set_directional_light(void* h, const double dir[3], const double color[3], double intensity) {
+    ((Scene*)h)->lights.clear();
+    orc_add_directional_light(h, dir, color, intensity);
+}
+// Triangle::new + world.entities.push (triangle.rs:19-23): a bare triangle as an entity of its own
+int orc_add_triangle(void* h, const double v0[3], const double v1[3], const double v2[3], const double n[3], int mat) {
+    Scene* s = (Scene*)h;
+    s->tri_ents.push_back(Scene::TriEnt{Triangle{{v0[0], v0[1], v0[2]}, {v1[0], v1[1], v1[2]}, {v2[0], v2[1], v2[2]}, {n[0], n[1], n[2]}}, mat});
+    s->ents.push_back(Entity{3, (int)s->tri_ents.size() - 1});
+    return (int)s->ents.size() - 1;
 }
 void orc_set_ambient(void* h, double a) { ((Scene*)h)->ambient = a; }
 
 // PointLight{position, color, brightness, attenuation} (lighting.rs:52-57); at most 16.
 int orc_add_point_light(void* h, const double pos[3], const double color[3], double brightness, double attenuation) {
     Scene* s = (Scene*)h;
-    if (s->point_lights.size() >= 16) return -1;
-    s->point_lights.push_back(Scene::PointLight{V3{pos[0], pos[1], pos[2]}, V3{color[0], color[1], color[2]}, brightness, attenuation});
-    return (int)s->point_lights.size() - 1;
+    size_t n_point = 0;
+    for (const Scene::Light& l : s->lights) n_point += l.kind == 1;
+    if (n_point >= 16 || s->lights.size() >= 32) return -1;
+    s->lights.push_back(Scene::Light{1, V3{pos[0], pos[1], pos[2]}, V3{color[0], color[1], color[2]}, brightness, attenuation});
+    return (int)s->lights.size() - 1;
 }
 void orc_set_shadow_mode(void* h, int mode) { ((Scene*)h)->shadow_mode = mode; }
 
@@ -946,6 +965,9 @@ static void translate_entity(Scene* s, int e, V3 v, bool refit) {
             m.tri_box[i] = t.bbox();        // instrumentation only (tri_box_hits); the tree does not read it again
         }
         translate_nodes(m.root.get(), v, refit);
+    } else if (ent.kind == 3) {                          // triangle.rs:79-83
+        Triangle& t = s->tri_ents[ent.index].tri;
+        t.v0 = add(t.v0, v); t.v1 = add(t.v1, v); t.v2 = add(t.v2, v);
     } else {
         Group& g = *s->groups[ent.index];
         for (int mem : g.members) translate_entity(s, mem, v, refit);

@@ -40,11 +40,11 @@ class Stats(C.Structure):
 EXPORTS = [
     "rrt_last_error", "rrt_version", "rrt_set_device", "rrt_device_image_support",
     "rrt_default_camera", "rrt_default_settings", "rrt_scene_create", "rrt_scene_destroy",
-    "rrt_add_material", "rrt_add_material_ext", "rrt_add_sphere", "rrt_add_mesh", "rrt_add_group", "rrt_set_sky_face",
-    "rrt_set_directional_light", "rrt_set_ambient", "rrt_add_point_light", "rrt_set_shadow_mode", "rrt_translate_entity",
+    "rrt_add_material", "rrt_add_material_ext", "rrt_add_sphere", "rrt_add_mesh", "rrt_add_triangle", "rrt_add_group", "rrt_set_sky_face",
+    "rrt_set_directional_light", "rrt_add_directional_light", "rrt_set_ambient", "rrt_add_point_light", "rrt_set_shadow_mode", "rrt_translate_entity",
     "rrt_occluded_rays", "rrt_set_work_budget", "rrt_set_cull_mode", "rrt_set_timing",
     "rrt_scene_commit",
-    "rrt_render", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_tile_skew", "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_gather_tiles", "rrt_assemble_tiles",
+    "rrt_render", "rrt_alloc_host_pinned", "rrt_free_host_pinned", "rrt_release_stream", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_tile_skew", "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_gather_tiles", "rrt_assemble_tiles",
     "rrt_trace_rays", "rrt_cast_rays", "rrt_get_stats", "rrt_mesh_tree_sizes",
     "rrt_mesh_tree_export", "rrt_cover_mask", "rrt_selftest_math", "rrt_philox4x32_10",
     "rrt_host_load_model", "rrt_host_add_model", "rrt_host_load_model_ex", "rrt_host_add_model_ex", "rrt_host_load_png_rgb8",
@@ -83,9 +83,11 @@ def _load():
     L.rrt_add_material_ext.argtypes = [vp, dp, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_double]
     L.rrt_add_sphere.argtypes = [vp, dp, C.c_double, i32]
     L.rrt_add_mesh.argtypes = [vp, vp, vp, i64, i32]
+    L.rrt_add_triangle.argtypes = [vp, dp, dp, dp, dp, i32]
     L.rrt_add_group.argtypes = [vp, vp, i32]
     L.rrt_set_sky_face.argtypes = [vp, i32, vp, u32, u32]
     L.rrt_set_directional_light.argtypes = [vp, dp, dp, C.c_double]
+    L.rrt_add_directional_light.argtypes = [vp, dp, dp, C.c_double]
     L.rrt_set_ambient.argtypes = [vp, C.c_double]
     L.rrt_add_point_light.argtypes = [vp, dp, dp, C.c_double, C.c_double]
     L.rrt_set_shadow_mode.argtypes = [vp, i32]
@@ -99,6 +101,11 @@ def _load():
     L.rrt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp, vp]
     L.rrt_render_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp, vp]
     L.rrt_noalloc_scratch_bytes.restype = u64
+    L.rrt_alloc_host_pinned.argtypes = [u64]
+    L.rrt_alloc_host_pinned.restype = vp
+    L.rrt_free_host_pinned.argtypes = [vp]
+    L.rrt_free_host_pinned.restype = None
+    L.rrt_release_stream.argtypes = [vp, vp]
     L.rrt_comm_unique_id.argtypes = [vp]
     L.rrt_comm_init.argtypes = [i32, i32, vp, C.POINTER(vp)]
     L.rrt_comm_destroy.argtypes = [vp]

@@ -109,16 +109,31 @@ struct DMaterial {
     double ior;
 };
 
-// PointLight{position, color, brightness, attenuation} (lighting.rs:52-57)
-struct DPointLight {
-    double pos[3];
+// One entry of world.light_sources (common.rs:12: Vec<Box<dyn LightSource>>), in push order -- the order Lambert and
+// Phong sum them in (lambert.rs:34-43, phong.rs:37-45).
+//   kind 0 DirectionalLight{direction (normalised by ::new, lighting.rs:26), color, intensity}  (lighting.rs:19-50)
+//   kind 1 PointLight{position, color, brightness, attenuation}                                  (lighting.rs:52-89)
+struct DLight {
+    int32_t kind;
+    int32_t pad;
+    double v[3];       // direction / position
     double color[3];
-    double brightness, attenuation;
+    double a, b;       // intensity, - / brightness, attenuation
 };
 constexpr int32_t kMaxPointLights = 16;
+constexpr int32_t kMaxLights = 32;
+
+// A bare Triangle pushed to world.entities (or into a Scene<T>) as an Entity of its own (triangle.rs:19-58): collided by
+// Triangle::collide directly -- no kd-tree around it, hence no root-box gate (aabb.rs:89) in front of the test.
+struct DTriEnt {
+    double v0[3], e1[3], e2[3];   // as DTri
+    double normal[3];             // the stored normal, returned as is (triangle.rs:54)
+    int32_t material;
+    int32_t pad;
+};
 
 struct DEntity {
-    int32_t kind;   // 0 sphere, 1 mesh, 2 group (Scene<T>); | kEntityMember when it lives inside a group
+    int32_t kind;   // 0 sphere, 1 mesh, 2 group (Scene<T>), 3 bare triangle; | kEntityMember when it lives inside a group
     int32_t index;
 };
 constexpr int32_t kEntityMember = 0x100;
@@ -159,6 +174,7 @@ struct DScene {
     const DMesh* meshes;
     const DMaterial* mats;
     const DGroup* groups;
+    const DTriEnt* tri_ents;
     int32_t n_groups;
     int32_t lds_mats;        // materials the trace kernels keep in LDS: all of them (<= kMaxLdsMats), or 0
 
@@ -181,8 +197,15 @@ struct DScene {
     const int32_t* mesh_stage;   // [n_meshes]: +-(LDS node offset + 1), negative for a breadth-first top; 0 = not staged
     int32_t cull_mode;       // 0 = off, 1 = on, 2 = verify (run both, count cull-vs-exact disagreements)
     int32_t lds_ents;        // 1: the trace kernels keep the entity table in LDS (n_ents <= kMaxLdsEnts)
-    const DPointLight* plights;   // world.light_sources behind the directional light, in push order
-    int32_t n_plights;
+    // world.light_sources in push order.  The reference's own world holds exactly one DirectionalLight (tracer.rs:55-65):
+    // then (and for a world without lights) has_light / light_* above are all the kernels read and general_lights is 0;
+    // any other list -- several directional lights, point lights, any order -- sets general_lights and the shading walks
+    // `lights` (the PL instantiations of the trace kernels).
+    const DLight* lights;
+    int32_t n_lights;
+    int32_t general_lights;
+    int32_t n_tri_ents;      // bare Triangle entities (DTriEnt): such worlds take the GROUPS ("general scene") kernels
+    int32_t pad_;
     int32_t shadow_mode;     // PointLight::visible: 0 = as the reference wrote it, 1 = corrected (rrt_set_shadow_mode)
 };
 
@@ -254,7 +277,8 @@ inline uint32_t tile_skew(uint32_t tiles_x, uint32_t world) {
 // ---- launchers (rrt_kernels.hip); all asynchronous on `stream` ------------
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream);
 void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream);
-void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream);
+void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream,
+                       uint32_t tile0 = 0, uint32_t n_tiles = 0);
 // Fills coverage mask `slot` of fr (zeroed by the caller) from the mesh's triangle stream (n entries).
 void launch_cover(const DMesh& mesh, int32_t n_entries, const DFrame& fr, uint32_t slot, void* stream);
 // Fills fr.tile_bins from the scene's spheres and the frame's coverage masks (after launch_cover).

@@ -632,8 +632,8 @@ struct Closest {
 #define RRT_LDS __attribute__((address_space(3)))
 constexpr int32_t kEntRec = 36;        // kind, index, the struct (<= 30 dwords), then for a mesh its mesh_stage word
 constexpr int32_t kEntRecStage = 32;
-static_assert(sizeof(DSphere) <= 4 * (kEntRecStage - 2) && sizeof(DMesh) <= 4 * (kEntRecStage - 2) && sizeof(DGroup) <= 4 * (kEntRecStage - 2),
-              "entity record too small");
+static_assert(sizeof(DSphere) <= 4 * (kEntRecStage - 2) && sizeof(DMesh) <= 4 * (kEntRecStage - 2) && sizeof(DGroup) <= 4 * (kEntRecStage - 2) &&
+              sizeof(DTriEnt) <= 4 * (kEntRecStage - 2), "entity record too small");
 // SMALL (kernel template parameter, = DScene::lds_ents): the entity table and the materials are in
 // LDS too.  A compile-time choice, so that the kernels of small scenes carry no global-memory
 // fallback (its five base pointers alone would sit in ten SGPRs through the whole kernel).
@@ -694,12 +694,29 @@ RRT_DEV T lds_uniform(const RRT_LDS uint32_t* p) {
 // loop (tracer.rs:183-188) and a kd leaf over entities (kdtree.rs:204-211) apply: strict <, so the
 // first of equals stays.
 // `rec` != nullptr: entity e's LDS record (e is wave-uniform then); nullptr: read from global memory.
-template <int CULL, bool REC, bool ANY = false>
+// GEN: the "general scene" instantiations (kernel template parameter GROUPS: Scene<T> groups, point lights or bare
+// Triangle entities present) also know entity kind 3; the kernels of the reference's own worlds carry none of it.
+template <int CULL, bool REC, bool ANY = false, bool GEN = false>
 RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LDS uint32_t* rec, int32_t e, DEntity ent,
                             V3 o, V3 d, int32_t medium, Closest* best, unsigned long long* stats, double lim2 = 0.0,
                             uint32_t cov = ~0u) {
     if ((RRT_ABL & 4) && ent.kind == 0) return;
     if ((RRT_ABL & 2) && ent.kind != 0) return;
+    if (GEN && ent.kind == 3) {
+        // Triangle::collide (triangle.rs:25-58) of a Triangle that is an entity of its own: the test itself, nothing
+        // in front of it (a mesh of one triangle would put its kd root box and the +0.001 nudge of aabb.rs:89 there)
+        DTriEnt T;
+        if constexpr (REC) T = lds_field<DTriEnt>(rec + 2, 0);
+        else T = sc.tri_ents[ent.index];
+        const TriData td{ld3(T.v0), ld3(T.e1), ld3(T.e2)};
+        double t;
+        if (tri_collide(td, o, d, &t)) {
+            const V3 pos = o + d * t;                  // triangle.rs:53
+            const double dist = mag2(pos - o);         // tracer.rs:184
+            if (dist < best->dist) { best->dist = dist; best->t = t; best->ent = e; best->entry = -1; }
+        }
+        return;
+    }
     if (ent.kind == 0) {
         double t;
         DSphere S;
@@ -788,15 +805,15 @@ RRT_DEV void group_collide(const DScene& sc, LDS lds, const DGroup& G, const DNo
                         if (CULL == 1 && binned) continue;
                         const RRT_LDS uint32_t* rec = lds.ents + eu * kEntRec;
                         DEntity ent = lds_uniform<DEntity>(rec);
-                        ent.kind &= ~kEntityMember;        // 0 sphere or 1 mesh (rrt_add_group admits nothing else)
-                        entity_collide<CULL, true, ANY>(sc, lnodes, rec, eu, ent, o, d, medium, &best, stats, lim2, cov);
+                        ent.kind &= ~kEntityMember;        // 0 sphere, 1 mesh or 3 bare triangle (rrt_add_group admits nothing else)
+                        entity_collide<CULL, true, ANY, true>(sc, lnodes, rec, eu, ent, o, d, medium, &best, stats, lim2, cov);
                         if (CULL == 2 && binned && best.ent == eu) atomicAdd(&stats[2], 1ull);
                     }
                 }
             } else {
                 DEntity ent = sc.ents[e];
                 ent.kind &= ~kEntityMember;
-                entity_collide<CULL, false, ANY>(sc, lnodes, nullptr, e, ent, o, d, medium, &best, stats, lim2, cov);   // e differs per lane
+                entity_collide<CULL, false, ANY, true>(sc, lnodes, nullptr, e, ent, o, d, medium, &best, stats, lim2, cov);   // e differs per lane
             }
             if (ANY && best.dist < lim2) break;
         }
@@ -847,7 +864,7 @@ RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, 
                 continue;
             }
         }
-        entity_collide<CULL, LDS::kSmall>(sc, lnodes, rec, e, ent, o, d, medium, best, stats, 0.0, cov);
+        entity_collide<CULL, LDS::kSmall, false, GROUPS>(sc, lnodes, rec, e, ent, o, d, medium, best, stats, 0.0, cov);
         if (CULL == 2 && binned && best->ent == e) atomicAdd(&stats[2], 1ull);    // verify mode: the bin must have been right
     }
 }
@@ -882,7 +899,7 @@ RRT_DEV bool any_hit(const DScene& sc, LDS lds, V3 o, V3 d, double lim2, unsigne
                 continue;
             }
         }
-        entity_collide<CULL, LDS::kSmall, true>(sc, lnodes, rec, e, ent, o, d, -1, &h, stats, lim2);
+        entity_collide<CULL, LDS::kSmall, true, GROUPS>(sc, lnodes, rec, e, ent, o, d, -1, &h, stats, lim2);
         if (LITERAL) { if (h.ent < 0) return true; }
         else if (h.ent >= 0 && h.dist < lim2) return true;
     }
@@ -917,8 +934,13 @@ RRT_DEV void finish_hit(const DScene& sc, LDS lds, V3 o, V3 d, const Closest& c,
     h->pos = o + d * c.t;
     if constexpr (LDS::kSmall) {
         const RRT_LDS uint32_t* rec = lds.ents + c.ent * kEntRec;
-        h->sphere = ((int32_t)rec[0] & ~kEntityMember) == 0;
-        if (h->sphere) {
+        const int32_t kind = (int32_t)rec[0] & ~kEntityMember;
+        h->sphere = kind == 0;
+        if (kind == 3) {         // a bare Triangle: its stored normal (triangle.rs:54); no triangle id (it is not part of a mesh)
+            h->normal = mk(lds_field<double>(rec, 8 + offsetof(DTriEnt, normal)), lds_field<double>(rec, 8 + offsetof(DTriEnt, normal) + 8),
+                           lds_field<double>(rec, 8 + offsetof(DTriEnt, normal) + 16));
+            h->mat = lds_field<int32_t>(rec, 8 + offsetof(DTriEnt, material));
+        } else if (h->sphere) {
             const V3 ctr = mk(lds_field<double>(rec, 8 + offsetof(DSphere, c)), lds_field<double>(rec, 8 + offsetof(DSphere, c) + 8),
                               lds_field<double>(rec, 8 + offsetof(DSphere, c) + 16));
             h->normal = normalize(h->pos - ctr);
@@ -935,7 +957,11 @@ RRT_DEV void finish_hit(const DScene& sc, LDS lds, V3 o, V3 d, const Closest& c,
         DEntity ent = sc.ents[c.ent];
         ent.kind &= ~kEntityMember;
         h->sphere = ent.kind == 0;
-        if (ent.kind == 0) {
+        if (ent.kind == 3) {
+            const DTriEnt* T = sc.tri_ents + ent.index;
+            h->normal = ld3(T->normal);
+            h->mat = T->material;
+        } else if (ent.kind == 0) {
             const DSphere* S = sc.spheres + ent.index;
             h->normal = normalize(h->pos - ld3(S->c));
             h->mat = S->material;
@@ -1033,31 +1059,44 @@ RRT_DEV void shade_direct(const DScene& sc, LDS lds, const DMaterial& m, V3 d, V
         L = ld3(sc.light_dir); lcolor = ld3(sc.light_color);
     }
     V3 fin = color * ambient;
-    const bool visible = sc.has_light && (dot(normal, L) < 0.);   // lighting.rs:43-45
     V3 lam = mk(0., 0., 0.), ph = mk(0., 0., 0.);
-    if (visible) {
-        double power = intensity * (m.albedo / 3.14159265358979323846) * -dot(normal, L);
-        power = fmax(power, 0.);
-        lam = lam + color * power;
-        const V3 bis = normalize(neg(L) - d);
-        const double pw = intensity * powi(fmax(dot(bis, normal), 0.), m.alpha);
-        ph = ph + lcolor * pw;
-    }
-    if constexpr (PL) {
-        for (int32_t k = 0; k < sc.n_plights; ++k) {
-            const DPointLight L = sc.plights[k];
-            const V3 lpos = ld3(L.pos);
-            if (!point_light_visible<CULL, GROUPS>(sc, lds, lpos, pos, normal, stats)) continue;
-            const V3 dir0 = pos - lpos;                                   // lighting.rs:61-67
-            const double distance2 = mag2(dir0);
-            const V3 dir = normalize(dir0);
-            const double lp = L.brightness / (L.attenuation * distance2);
+    if constexpr (!PL) {
+        // world.light_sources = [one DirectionalLight] (what new_empty_world builds, tracer.rs:55-65), or empty
+        const bool visible = sc.has_light && (dot(normal, L) < 0.);   // lighting.rs:43-45
+        if (visible) {
+            double power = intensity * (m.albedo / 3.14159265358979323846) * -dot(normal, L);
+            power = fmax(power, 0.);
+            lam = lam + color * power;
+            const V3 bis = normalize(neg(L) - d);
+            const double pw = intensity * powi(fmax(dot(bis, normal), 0.), m.alpha);
+            ph = ph + lcolor * pw;
+        }
+    } else {
+        // any other list: every light in push order, each adding its Lambert term to one sum and its Phong term to
+        // the other (lambert.rs:34-43, phong.rs:37-45 -- two loops over the same list, the same visible() answers)
+        (void)L; (void)lcolor; (void)intensity;
+        for (int32_t k = 0; k < sc.n_lights; ++k) {
+            const DLight Lk = sc.lights[k];
+            V3 dir;
+            double lp;
+            if (Lk.kind == 0) {                                           // DirectionalLight, lighting.rs:35-45
+                dir = ld3(Lk.v);
+                if (!(dot(normal, dir) < 0.)) continue;
+                lp = Lk.a;
+            } else {                                                      // PointLight, lighting.rs:60-84
+                const V3 lpos = ld3(Lk.v);
+                if (!point_light_visible<CULL, GROUPS>(sc, lds, lpos, pos, normal, stats)) continue;
+                const V3 dir0 = pos - lpos;
+                const double distance2 = mag2(dir0);
+                dir = normalize(dir0);
+                lp = Lk.a / (Lk.b * distance2);
+            }
             double power = lp * (m.albedo / 3.14159265358979323846) * -dot(normal, dir);
             power = fmax(power, 0.);
             lam = lam + color * power;
             const V3 bis = normalize(neg(dir) - d);
             const double pw = lp * powi(fmax(dot(bis, normal), 0.), m.alpha);
-            ph = ph + ld3(L.color) * pw;
+            ph = ph + ld3(Lk.color) * pw;
         }
     }
     *A = fin + lam * m.mixL;
@@ -1474,8 +1513,10 @@ RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned 
             const int32_t kind = ent.kind & ~kEntityMember;
             const uint32_t* src = kind == 0   ? (const uint32_t*)(sc.spheres + ent.index)
                                   : kind == 1 ? (const uint32_t*)(sc.meshes + ent.index)
+                                  : kind == 3 ? (const uint32_t*)(sc.tri_ents + ent.index)
                                               : (const uint32_t*)(sc.groups + ent.index);
-            const int32_t n = kind == 0 ? (int32_t)sizeof(DSphere) / 4 : kind == 1 ? (int32_t)sizeof(DMesh) / 4 : (int32_t)sizeof(DGroup) / 4;
+            const int32_t n = kind == 0 ? (int32_t)sizeof(DSphere) / 4 : kind == 1 ? (int32_t)sizeof(DMesh) / 4
+                              : kind == 3 ? (int32_t)sizeof(DTriEnt) / 4 : (int32_t)sizeof(DGroup) / 4;
             uint32_t v = 0u;
             if (w == 0) v = (uint32_t)ent.kind;
             else if (w == 1) v = (uint32_t)ent.index;
@@ -1765,11 +1806,11 @@ RRT_DEV void accumulate_trip(const DWork& wk, const DFrame& fr, const double* by
 // accum[lp] (+)= sum over this batch's samples, in sample order (deterministic: the oracle's loop).
 // FINAL (the frame's last batch): the sum goes straight into the pixel instead of back to accum.
 template <bool FINAL>
-__global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr, uint8_t* d_rgb8, double* d_color) {
+__global__ __launch_bounds__(256) void k_accumulate(DWork wk, DFrame fr, uint8_t* d_rgb8, double* d_color, uint32_t block0) {
     __shared__ double by255[256];
     by255[threadIdx.x] = (double)threadIdx.x / 255.0;          // cubemap.rs:70-74, one IEEE division per thread
     __syncthreads();
-    const uint32_t lp = blockIdx.x * 256u + threadIdx.x;       // grid = npx_local / 256 exactly
+    const uint32_t lp = (blockIdx.x + block0) * 256u + threadIdx.x;   // grid = npx_local / 256 exactly, or a band of tile rows (block0 = its first tile)
     const uint32_t N = fr.npx_local;
     const uint32_t pp = (lp & ~255u) | tile_unswz(lp & 255u);   // where the trace kernels put this pixel's samples
     V3 acc = mk(0., 0., 0.);
@@ -1807,11 +1848,11 @@ RRT_DEV double quad_bcast(double v, int j) {
 }
 
 template <bool FINAL>
-__global__ __launch_bounds__(256) void k_accumulate_quad(DWork wk, DFrame fr, uint8_t* d_rgb8, double* d_color) {
+__global__ __launch_bounds__(256) void k_accumulate_quad(DWork wk, DFrame fr, uint8_t* d_rgb8, double* d_color, uint32_t block0) {
     __shared__ double by255[256];
     by255[threadIdx.x] = (double)threadIdx.x / 255.0;          // cubemap.rs:70-74, one IEEE division per thread
     __syncthreads();
-    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;      // grid = npx_local / 64 exactly
+    const uint32_t gid = (blockIdx.x + block0) * 256u + threadIdx.x;  // grid = npx_local / 64 exactly, or a band (block0 = 4 x its first tile)
     const uint32_t lp = gid >> 2, sub = gid & 3u;
     const uint32_t N = fr.npx_local;
     const uint32_t pp = (lp & ~255u) | tile_unswz(lp & 255u);
@@ -1982,6 +2023,30 @@ __global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint
                 // written so that a NaN anywhere keeps the bit
                 if (pxhi < x0 || pxlo >= x1 || pyhi < y0 || pylo >= y1) may = false;
             }
+        } else if (kind == 3) {
+            // a bare Triangle: k_cover's projection (see there) with the triangle's own constants -- S its longer edge,
+            // R >= the distance from the eye to any of its points
+            const DTriEnt T = sc.tri_ents[ent.index];
+            const V3 eye = mk(p.eye[0], p.eye[1], p.eye[2]);
+            const V3 v0 = ld3(T.v0) - eye, v1 = (ld3(T.v0) + ld3(T.e1)) - eye, v2 = (ld3(T.v0) + ld3(T.e2)) - eye;
+            const double S = sqrt(fmax(mag2(ld3(T.e1)), mag2(ld3(T.e2)))) * (1.0 + 1e-9);
+            const double R = fabs(v0.x) + fabs(v0.y) + fabs(v0.z) + S;
+            const double amax = fmax(fmax(fabs(T.v0[0]), fabs(T.v0[1])), fabs(T.v0[2])) + S;
+            const double omax = fmax(fmax(fabs(p.eye[0]), fabs(p.eye[1])), fabs(p.eye[2]));
+            const double delta = 2.0 * (2.5e-7 * S * S * 1.7320508075688774 * (R + S)) * 1.000001 + 1e-9 * (omax + amax) + 1e-300;
+            const double z_near = 4.0 * (8e-8 * S * S * (R + S)) * 1.000001 + 1e-9 * (omax + amax) + 1e-300;
+            const double zmin = fmin(v0.z, fmin(v1.z, v2.z)) - delta;
+            if (zmin > z_near) {                                 // (false for NaN: the bit stays)
+                const double u0 = v0.x / v0.z, u1 = v1.x / v1.z, u2 = v2.x / v2.z;
+                const double w0 = v0.y / v0.z, w1 = v1.y / v1.z, w2 = v2.y / v2.z;
+                const double ulo = fmin(u0, fmin(u1, u2)), uhi = fmax(u0, fmax(u1, u2));
+                const double wlo = fmin(w0, fmin(w1, w2)), whi = fmax(w0, fmax(w1, w2));
+                const double g = 2.0 * delta / zmin;
+                const double mu = g * (1.0 + fmax(fabs(ulo), fabs(uhi))), mw = g * (1.0 + fmax(fabs(wlo), fabs(whi)));
+                const double pxlo = (ulo - mu) * sx + 0.5 * (double)p.width - 1.0, pxhi = (uhi + mu) * sx + 0.5 * (double)p.width + 1.0;
+                const double pylo = (wlo - mw) * sy + 0.5 * (double)p.height - 1.0, pyhi = (whi + mw) * sy + 0.5 * (double)p.height + 1.0;
+                if (pxhi < x0 || pxlo >= x1 || pyhi < y0 || pylo >= y1) may = false;      // a NaN anywhere keeps the bit
+            }
         } else if (kind == 1) {
             const int32_t cs = (sc.meshes[ent.index].flags >> kCoverShift) & 15;
             if (cs != 0 && (uint32_t)cs <= n_cover) {
@@ -2129,12 +2194,13 @@ inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) 
 
 }  // namespace
 
-// Kernel variant by scene: cull mode x (Scene<T> groups present) x (entity table in LDS) x (point lights present).
-// A world with point lights always takes the GROUPS instantiation (it handles group-less worlds too), so the
+// Kernel variant by scene: cull mode x (general scene: Scene<T> groups or bare Triangle entities present) x (entity
+// table in LDS) x (general light list: anything but the reference's single DirectionalLight).
+// A world with a general light list always takes the GROUPS instantiation (it handles group-less worlds too), so the
 // shadow-ray code is compiled 6 times per kernel, not 12.
 #define RRT_PICK(name)                                                                                           \
     [&]() {                                                                                                      \
-        const bool pl = sc.n_plights > 0, g = sc.n_groups > 0 || pl, sm = sc.lds_ents != 0;                      \
+        const bool pl = sc.general_lights != 0, g = sc.n_groups > 0 || sc.n_tri_ents > 0 || pl, sm = sc.lds_ents != 0;  \
         const int c = sc.cull_mode;                                                                              \
         if (pl) {                                                                                                \
             if (sm) return c == 0 ? name<0, true, true, true> : c == 1 ? name<1, true, true, true> : name<2, true, true, true>;      \
@@ -2169,14 +2235,18 @@ void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t
     auto k = RRT_PICK(k_wave_bounce);
     hipLaunchKernelGGL(k, dim3(bounce_grid()), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
 }
-void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream) {
+void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream,
+                       uint32_t tile0, uint32_t n_tiles) {
+    // tile slots [tile0, tile0 + n_tiles) of this rank (n_tiles = 0: all of them).  rrt_render resolves the frame in
+    // bands of tile rows, so that a band's pixels travel to the host while the next band is resolved.
+    if (n_tiles == 0u) { tile0 = 0u; n_tiles = fr.npx_local / 256u; }
     if (fr.pack_log2 >= 4u) {
-        hipLaunchKernelGGL(final_batch ? k_accumulate_quad<true> : k_accumulate_quad<false>, dim3(fr.npx_local / 64), dim3(256), 0,
-                           (hipStream_t)stream, wk, fr, d_rgb8, d_color);
+        hipLaunchKernelGGL(final_batch ? k_accumulate_quad<true> : k_accumulate_quad<false>, dim3(4u * n_tiles), dim3(256), 0,
+                           (hipStream_t)stream, wk, fr, d_rgb8, d_color, 4u * tile0);
         return;
     }
-    hipLaunchKernelGGL(final_batch ? k_accumulate<true> : k_accumulate<false>, dim3(fr.npx_local / 256), dim3(256), 0,
-                       (hipStream_t)stream, wk, fr, d_rgb8, d_color);
+    hipLaunchKernelGGL(final_batch ? k_accumulate<true> : k_accumulate<false>, dim3(n_tiles), dim3(256), 0,
+                       (hipStream_t)stream, wk, fr, d_rgb8, d_color, tile0);
 }
 void launch_cover(const DMesh& mesh, int32_t n_entries, const DFrame& fr, uint32_t slot, void* stream) {
     if (n_entries <= 0) return;
@@ -2223,18 +2293,18 @@ void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t
 }
 void launch_trace_rays(const DScene& sc, const double* d_rays, int64_t n, int32_t* ent, int32_t* tri, double* t,
                        double* pos, double* nrm, unsigned long long* stats, void* stream) {
-    hipLaunchKernelGGL(sc.n_groups > 0 ? k_trace_rays<true> : k_trace_rays<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sc, d_rays,
+    hipLaunchKernelGGL(sc.n_groups > 0 || sc.n_tri_ents > 0 ? k_trace_rays<true> : k_trace_rays<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sc, d_rays,
                        n, ent, tri, t, pos, nrm, stats);
 }
 void launch_cast_rays(const DScene& sc, const double* d_rays, int64_t n, uint32_t max_bounce, uint32_t prune,
                       double* color, unsigned long long* stats, void* stream) {
-    auto k = sc.n_plights > 0 ? k_cast_rays<true, true> : sc.n_groups > 0 ? k_cast_rays<true, false> : k_cast_rays<false, false>;
+    auto k = sc.general_lights ? k_cast_rays<true, true> : sc.n_groups > 0 || sc.n_tri_ents > 0 ? k_cast_rays<true, false> : k_cast_rays<false, false>;
     hipLaunchKernelGGL(k, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sc, d_rays, n, max_bounce, prune,
                        color, stats);
 }
 void launch_occluded_rays(const DScene& sc, const double* d_rays, const double* d_lim2, int64_t n, uint8_t* out,
                           unsigned long long* stats, void* stream) {
-    hipLaunchKernelGGL(sc.n_groups > 0 ? k_occluded_rays<true> : k_occluded_rays<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(sc.n_groups > 0 || sc.n_tri_ents > 0 ? k_occluded_rays<true> : k_occluded_rays<false>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, sc, d_rays, d_lim2, n, out, stats);
 }
 void launch_selftest(int op, const double* a, const double* b, int64_t n, double* out, void* stream) {

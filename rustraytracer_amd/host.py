@@ -111,6 +111,10 @@ class World:
             raise ValueError("verts / normals triangle counts differ")
         return B.check(B.lib.rrt_add_mesh(self.h, _ptr(v), _ptr(n), v.shape[0], mat))
 
+    def add_triangle(self, v0, v1, v2, normal, mat):
+        """Triangle::new + push (triangle.rs:19-23): a bare triangle as an entity of its own."""
+        return B.check(B.lib.rrt_add_triangle(self.h, _d3(v0), _d3(v1), _d3(v2), _d3(normal), mat))
+
     def add_group(self, members):
         """Scene::new over entities already added (scene.rs:39-47); returns the group's entity id."""
         m = np.ascontiguousarray(members, dtype=np.int32)
@@ -126,6 +130,10 @@ class World:
 
     def set_directional_light(self, direction, color, intensity):
         B.check(B.lib.rrt_set_directional_light(self.h, _d3(direction), _d3(color), float(intensity)))
+
+    def add_directional_light(self, direction, color, intensity):
+        """DirectionalLight::new + world.light_sources.push (lighting.rs:25-32): appends; returns the light's index."""
+        return B.check(B.lib.rrt_add_directional_light(self.h, _d3(direction), _d3(color), float(intensity)))
 
     def set_ambient(self, a):
         B.check(B.lib.rrt_set_ambient(self.h, float(a)))

@@ -246,3 +246,71 @@ def test_point_light_known_answers(O, scenes):
     # any-hit query: limits before / behind the hit
     c = build(False)
     assert list(c.occluded_rays(np.repeat(ray, 3, axis=0), [63.9, 64.0, 64.1])) == [0, 0, 1]
+
+
+def test_light_list_and_bare_triangle_known_answers(O, scenes):
+    """world.light_sources is summed in push order (lambert.rs:34-43, phong.rs:37-45), and a bare Triangle entity
+    answers with Triangle::collide and its STORED normal (triangle.rs:25-58).  Neither has a golden in the reference
+    (main.rs holds one light and no bare triangle), so the oracle's restatement is pinned to the formulas evaluated by
+    hand in numpy: two directional lights with a point light between them shining on an axis-aligned triangle."""
+    import numpy as np
+    from oracle import oracle as Om
+    dot = lambda a, b: (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+    norm = lambda v: v * (1.0 / np.sqrt(dot(v, v)))
+    color, albedo, mixL, mixP, alpha = np.array([0.5, 0.25, 0.125]), 0.8, 0.9, 0.5, 20
+    lights = [("d", np.array([1.0, -1.0, 1.0]), np.array([0.9, 0.9, 0.9]), 2.0, 0.0),
+              ("p", np.array([3.0, -5.0, 3.0]), np.array([1.0, 0.5, 0.25]), 300.0, 2.0),
+              ("d", np.array([-0.3, 0.2, 1.0]), np.array([0.2, 0.4, 1.0]), 0.7, 0.0)]
+
+    def build(order):
+        c = Om.OracleScene()
+        c.set_sky(Om.load_cubemap(os.path.join(scenes.ASSETS, "cubemaps", "sky")))
+        m = c.add_material(color, albedo, mixL, 0.0, mixP, alpha)
+        # axis-aligned (z = 10), stored normal deliberately not unit length: returned as stored
+        e = c.add_triangle((-4.0, -4.0, 10.0), (4.0, -4.0, 10.0), (0.0, 6.0, 10.0), (0.0, 0.0, -1.25), m)
+        assert e == 0
+        for k in order:
+            kind, v, col, a, b = lights[k]
+            if kind == "d":
+                c.add_directional_light(v, col, a)
+            else:
+                c.add_point_light(v, col, a, b)
+        c.set_shadow_mode(1)
+        return c
+
+    ray = np.array([[0.0, 0.0, 0.0, 0.0, 0.0, 1.0]])
+    pos, n, d = np.array([0.0, 0.0, 10.0]), np.array([0.0, 0.0, -1.25]), np.array([0.0, 0.0, 1.0])
+
+    def expect(order):
+        lam, ph = np.zeros(3), np.zeros(3)
+        for k in order:
+            kind, v, col, a, b = lights[k]
+            if kind == "d":
+                dirn, power = norm(v), a
+                if not dot(n, dirn) < 0.0:
+                    continue
+            else:
+                dir0 = pos - v
+                assert dot(n, dir0) < 0.0                    # faces the light, nothing in between: visible
+                dirn, power = norm(dir0), a / (b * dot(dir0, dir0))
+            lam = lam + color * max(power * (albedo / np.pi) * -dot(n, dirn), 0.0)
+            x = max(dot(norm(-dirn - d), n), 0.0)
+            x2 = x * x; x4 = x2 * x2; x8 = x4 * x4; x16 = x8 * x8
+            ph = ph + col * (power * (x4 * x16))
+        return (color * 0.15 + lam * mixL) + ph * mixP
+
+    tr = build((0,)).trace_rays(ray)
+    assert tr["ent"][0] == 0 and tr["tri"][0] == -1 and tr["t"][0] == 10.0
+    assert np.array_equal(tr["normal"][0], n) and np.array_equal(tr["pos"][0], pos)
+    results = {}
+    for order in ((0,), (0, 1), (0, 1, 2), (2, 1, 0), (1, 2, 0)):
+        got = build(order).cast_rays(ray, 0, 1)[0]
+        assert np.array_equal(got, expect(order)), order
+        results[order] = got
+    assert not np.array_equal(results[(0, 1, 2)], results[(0, 1)])
+    # the triangle pushed as a one-triangle Model instead is never seen: its kd root box is flat (aabb.rs:89)
+    c = Om.OracleScene()
+    c.set_sky(Om.load_cubemap(os.path.join(scenes.ASSETS, "cubemaps", "sky")))
+    m = c.add_material(color, albedo, mixL, 0.0, mixP, alpha)
+    c.add_mesh(np.array([[[-4.0, -4.0, 10.0], [4.0, -4.0, 10.0], [0.0, 6.0, 10.0]]]), np.array([[0.0, 0.0, -1.0]]), m)
+    assert c.trace_rays(ray)["ent"][0] == -1

@@ -58,6 +58,10 @@ if v:
     r["executed"] = {"valu_busy": v["valu_busy"], "lane_utilisation": v["lane_utilisation"],
                      "issue_slot_frac": v["valu_busy"] * (v["lane_utilisation"] or 0.0), "waves_per_simd": v["waves_per_simd"],
                      "avg_launch_ns": v["avg_launch_ns"], "source": "profiles/valu_busy%s.json: %s" % (sfx, v.get("source"))}
+    if v.get("valu_wave_insts"):
+        r["issue_floor_ms"] = v["valu_wave_insts"] * 4.0 / (1024 * 2.4e9) * 1e3
+        r["launch_ms"] = v["avg_launch_ns"] * 1e-6
+        r["issue_floor_frac"] = r["issue_floor_ms"] / r["launch_ms"]
 json.dump(d, open(f, "w"))
 PY
 ls -la profiles
