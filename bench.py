@@ -384,13 +384,26 @@ def main():
         from rustraytracer_amd import binding as B
         rgb = np.zeros((h, w, 3), np.uint8)
         cam = Hst.default_camera()
-        st = Hst.make_settings(w, h, spp=spp0, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune, batch_spp=args.batch_spp)
         n_host = max(2, min(args.steps, 5))
-        for it in range(n_host + 1):
-            if it == 1:
-                th = time.perf_counter()
-            B.check(B.lib.rrt_render(scene.h, C.byref(cam), C.byref(st), rgb.ctypes.data_as(C.c_void_p), None, None, None))
-        host_ms = (time.perf_counter() - th) / n_host * 1e3
+        nbytes = h * w * 3
+        pin_p = B.lib.rrt_alloc_host_pinned(nbytes)
+        pin = np.frombuffer((C.c_ubyte * nbytes).from_address(pin_p), dtype=np.uint8).reshape(h, w, 3)
+
+        def host_ms_of(spp_h, buf):
+            st_h = Hst.make_settings(w, h, spp=spp_h, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune, batch_spp=args.batch_spp)
+            for it in range(n_host + 1):
+                if it == 1:
+                    th = time.perf_counter()
+                B.check(B.lib.rrt_render(scene.h, C.byref(cam), C.byref(st_h), buf.ctypes.data_as(C.c_void_p), None, None, None))
+            return (time.perf_counter() - th) / n_host * 1e3
+        host_ms = host_ms_of(spp0, rgb)                 # pageable destination (a Vec, a numpy array)
+        host_pinned_ms = host_ms_of(spp0, pin)          # page-locked destination (rrt_alloc_host_pinned): banded copies under the resolve
+        if side16 is not None:
+            side16["host_buffer_ms_per_step"] = host_ms_of(side16_spp, rgb)
+            side16["host_pinned_ms_per_step"] = host_ms_of(side16_spp, pin)
+        del pin
+        B.lib.rrt_free_host_pinned(pin_p)
+        st = Hst.make_settings(w, h, spp=spp0, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune, batch_spp=args.batch_spp)
         # restore the stats of a device frame (rrt_render overwrote them with identical counters; timings differ)
         scene.set_timing(2)
         scene.render_device(st, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
@@ -470,6 +483,7 @@ def main():
                 "rays_per_step": other["rays_per_step"], "timing": other["timing"]}
         if host_ms is not None:
             line["config"]["host_buffer_ms_per_step"] = host_ms      # rrt_render: + D2H of the RGB8 frame, blocking
+            line["config"]["host_pinned_ms_per_step"] = host_pinned_ms   # the same into page-locked memory
         if side16 is not None:
             line["configs1_16spp"] = side16
         if rank_share is not None:
