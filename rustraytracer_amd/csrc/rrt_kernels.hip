@@ -664,7 +664,8 @@ constexpr NoLds kNoLds{};
 // select chains.  From LDS they arrive where they are used, as VGPR operands: indices in doubles.
 constexpr int32_t kCLightDir = 0, kCLightColor = 3, kCIntensity = 6, kCAmbient = 7, kCEye = 8, kCLensZ = 11,
                   kCLensW = 12, kCLensH = 13, kCFaces = 14 /* 6 x {ptr, w, h}: 2 doubles each */,
-                  kCCover = 26 /* {ptr, n_cover, cover_stride, cover_bytes, -}: 3 doubles */, kCDoubles = 29;
+                  kCCover = 26 /* {ptr, n_cover, cover_stride, cover_bytes, -}: 3 doubles */,
+                  kCRcpW = 29 /* RN(1 / width), RN(1 / height), camera scale M (sky_texel_fast) */, kCRcpH = 30, kCScale = 31, kCDoubles = 32;
 RRT_DEV V3 ld3l(const RRT_LDS double* p) { return V3{p[0], p[1], p[2]}; }
 
 // Per-lane read of a field of an LDS-staged struct (the record index differs per lane).
@@ -994,9 +995,11 @@ __device__ const By255 kBy255{};
 
 // cubemap() + CubemapBehavior::compute (cubemap.rs:84-164, 56-77)
 // The texel cubemap() lands on, packed r | g << 8 | b << 16.
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
+// one unaligned dword instead of three byte loads (the face buffers carry 4 spare bytes at the end)
+RRT_DEV uint32_t ld_texel(const RRT_GLOBAL uint8_t* p) { return *(const RRT_GLOBAL u32_unaligned*)p & 0x00ffffffu; }
 template <class LDS>
-RRT_DEV uint32_t sky_texel(const DScene& sc, LDS lds, V3 dir) {
-    if (RRT_ABL & 1) return 0u;
+RRT_DEV const RRT_GLOBAL uint8_t* sky_texel_ptr(const DScene& sc, LDS lds, V3 dir) {
     const double x = dir.x, y = dir.y, z = dir.z;
     const double ax = fabs(x), ay = fabs(y), az = fabs(z);
     const bool xp = x > 0.0, yp = y > 0.0, zp = z > 0.0;
@@ -1023,10 +1026,12 @@ RRT_DEV uint32_t sky_texel(const DScene& sc, LDS lds, V3 dir) {
     uint32_t px = sat_u32(u * (double)w), py = sat_u32(v * (double)hgt);
     if (px >= w) px = w - 1;
     if (py >= hgt) py = hgt - 1;
-    // one unaligned dword instead of three byte loads (the face buffers carry 4 spare bytes at the end)
-    typedef uint32_t u32_unaligned __attribute__((aligned(1)));
-    const RRT_GLOBAL uint8_t* p = as_global(face) + ((size_t)py * w + px) * 3;
-    return *(const RRT_GLOBAL u32_unaligned*)p & 0x00ffffffu;
+    return as_global(face) + ((size_t)py * w + px) * 3;
+}
+template <class LDS>
+RRT_DEV uint32_t sky_texel(const DScene& sc, LDS lds, V3 dir) {
+    if (RRT_ABL & 1) return 0u;
+    return ld_texel(sky_texel_ptr(sc, lds, dir));
 }
 // CubemapBehavior::compute's rgb / 255.0 (cubemap.rs:70-74) through the 256-entry quotient table
 template <class LDS>
@@ -1244,6 +1249,90 @@ RRT_DEV void primary_ray(const DFrame& fr, LDS lds, uint32_t x, uint32_t y, uint
     *d = normalize(lp - eye);
 }
 
+// The sky texel of a primary ray WITHOUT the ray: for a primary ray that ends in the sky only the texel it lands on
+// matters (its colour is texel / 255), and four primary rays of five do.  The reference's chain -- (x + jx) / W, the
+// lens point, normalize (a square root and a reciprocal), two divisions uc / max, u * w truncated (tracer.rs:126-131,
+// cubemap.rs:84-164, 63-74) -- costs ~280 f64 instructions a wave, most of them in five correctly rounded divisions
+// and a square root whose last bits cannot matter unless the lookup lands within 1e-13 of a texel boundary.  This
+// evaluates the same chain with cheap divisions (f32 reciprocal + one Newton step in f64: relative error < 2^-40) and
+// without the normalisation (uc / max is scale invariant), bounds what that can move, and answers only when the
+// texel is beyond doubt:
+//   * fx, fy: a * RN(1/W) differs from RN(a / W) by < 2^-51 relative; the un-normalised direction v = lp - eye is
+//     formed with the reference's own operations, so |vF - v| < 2^-49 M per component (M = |eye| + lens_z + lens_w +
+//     lens_h); the reference's d = v * s(1 + e), |e| < 2^-51, one s > 0 for the three components.
+//   * face: max = the largest |component| of vF must exceed 2^-10 M (so |vF - v| < 2^-39 max) and the other two by
+//     a relative margin of 2^-30: then the same component is the largest of |d| with no tie (cubemap.rs:99-157
+//     decides ties by statement order; they all go to the exact path), and its sign is the sign the reference tests.
+//   * u: the true ratios of v and of vF differ by < 2^-38; the cheap division (y0 = rcp_f32(max), |y0 max - 1| <
+//     2^-22; one Newton step: relative error (y0 max - 1)^2 < 2^-44) adds < 2^-43; the reference's own roundings of
+//     d, the quotient, + 1.0, * 0.5 and * w add < 2^-49: |qF - q| < 2^-37, and with w <= 2^16: |tF - t| < 2^-21 texels.
+//   * the answer is given when tF lies more than 2^-16 texels (thirty times that bound) inside (k, k + 1) for an
+//     integer 0 <= k < w: truncation then yields k on both sides and the clamp to w - 1 is moot.
+// Anything else -- a doubtful face, a texel boundary within 2^-16, a face wider than 65536, a non-finite value --
+// returns false and the caller runs the exact chain.  A wave falls back about once in 10^3 (two axes, 64 lanes,
+// 2^-15 of a texel each).  cull_mode 2 computes both for every primary ray that ends in the sky and counts
+// disagreements in cull_violations (expected and tested: 0).
+RRT_DEV bool cheap_ratio(double num, double den, double* q) {      // den > 0; |num| <= den
+    const float df = (float)den;
+    const double y0 = (double)__builtin_amdgcn_rcpf(df);
+    const double r0 = num * y0;
+    const double e = __builtin_fma(-r0, den, num);
+    *q = __builtin_fma(e, y0, r0);
+    return df > 0x1p-100f && df < 0x1p100f;
+}
+template <class LDS>
+RRT_DEV bool sky_texel_fast(const DFrame& fr, LDS lds, uint32_t x, uint32_t y, uint32_t sample, const RRT_GLOBAL uint8_t** texel) {
+    if constexpr (!LDS::kStaged) {
+        return false;
+    } else {
+        if (RRT_ABL & 1) return false;
+        double jx = 0.0, jy = 0.0;
+        if (sample != 0u && !(RRT_ABL & 8)) {
+            uint32_t r[4];
+            philox4x32_10(y * fr.width + x, sample, 0u, 0u, fr.seed_lo, fr.seed_hi, r);
+            jx = (double)r[0] * (1.0 / 4294967296.0);
+            jy = (double)r[1] * (1.0 / 4294967296.0);
+        }
+        const V3 eye = ld3l(lds.consts + kCEye);
+        const double lens_z = lds.consts[kCLensZ], lens_w = lds.consts[kCLensW], lens_h = lds.consts[kCLensH];
+        const double M = lds.consts[kCScale];
+        const double fx = ((double)x + jx) * lds.consts[kCRcpW];
+        const double fy = ((double)y + jy) * lds.consts[kCRcpH];
+        // tracer.rs:84-110, 128-131 with the reference's operations (primary_ray above)
+        const V3 lens_pos = eye + mk(0.0, 0.0, lens_z);
+        const V3 ll = lens_pos - mk(lens_w / 2.0, lens_h / 2.0, 0.0);
+        const V3 lp = (ll + mk(lens_w, 0.0, 0.0) * fx) + mk(0.0, lens_h, 0.0) * fy;
+        const V3 v = lp - eye;
+        const double ax = fabs(v.x), ay = fabs(v.y), az = fabs(v.z);
+        const double ma = fmax(ax, fmax(ay, az));
+        const double lim = ma * (1.0 - 0x1p-30);
+        // exactly one component above lim: the winner; (a NaN makes every comparison false: no winner)
+        const bool wx = ax > lim, wy = ay > lim, wz = az > lim;
+        const int winners = (wx ? 1 : 0) + (wy ? 1 : 0) + (wz ? 1 : 0);
+        if (winners != 1 || !(ma > 0x1p-10 * M) || !(ma < 0x1p100)) return false;
+        double uc, vc;
+        uint32_t idx;
+        if (wx) { const bool pos = v.x > 0.0; uc = pos ? -v.z : v.z; vc = v.y; idx = pos ? 0u : 1u; }            // cubemap.rs:99-117
+        else if (wy) { const bool pos = v.y > 0.0; uc = v.x; vc = pos ? -v.z : v.z; idx = pos ? 2u : 3u; }       // :119-137
+        else { const bool pos = v.z > 0.0; uc = pos ? v.x : -v.x; vc = v.y; idx = pos ? 4u : 5u; }              // :139-157
+        double qu, qv;
+        const bool ok = cheap_ratio(uc, ma, &qu) & cheap_ratio(vc, ma, &qv);
+        const RRT_LDS uint32_t* f = (const RRT_LDS uint32_t*)(lds.consts + kCFaces) + 4u * idx;
+        const uint32_t w = f[2], hgt = f[3];
+        const double tu = (0.5 * (qu + 1.0)) * (double)w, tv = (0.5 * (qv + 1.0)) * (double)hgt;
+        const double ku = floor(tu), kv = floor(tv);
+        const double du = tu - ku, dv = tv - kv;
+        // strictly inside a texel on both axes, the texel inside the face (negated comparisons: a NaN fails them)
+        if (!ok || w > 65536u || hgt > 65536u || !(du > 0x1p-16 && du < 1.0 - 0x1p-16 && dv > 0x1p-16 && dv < 1.0 - 0x1p-16) ||
+            !(ku >= 0.0 && ku < (double)w && kv >= 0.0 && kv < (double)hgt))
+            return false;
+        const uint32_t px = (uint32_t)ku, py = (uint32_t)kv;
+        const uint8_t* face = lds_field<const uint8_t*>(f, 0);
+        *texel = as_global(face) + ((size_t)py * w + px) * 3;
+        return true;
+    }
+}
+
 // Which pixel of its 32x8 tile thread t of a trace block takes.  Storage (accum, the compact tile
 // buffer) stays row-major inside the tile; only the thread -> pixel assignment is swizzled, so that a
 // wave covers a compact footprint: its 64 rays then mostly enter the same leaves.
@@ -1422,7 +1511,13 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             // texel bytes ARE the colour -- 4 bytes go to samp32 instead of 24 to samp, and k_accumulate
             // looks the quotients up.
             CNT(8);
-            at_off<uint32_t>(wk.samp32, tag_off) = kSampTexel | sky_texel(sc, lds, d);
+            const RRT_GLOBAL uint8_t* tp = sky_texel_ptr(sc, lds, d);
+            const uint32_t texel = (RRT_ABL & 1) ? 0u : ld_texel(tp);
+            if (CULL == 2) {     // verify mode: the cheap lookup of the sky-only arm, where it answers, must name this texel
+                const RRT_GLOBAL uint8_t* tf;
+                if (sky_texel_fast(fr, lds, pixel % fr.width, pixel / fr.width, sample, &tf) && tf != tp) atomicAdd(&wk.stats[2], 1ull);
+            }
+            at_off<uint32_t>(wk.samp32, tag_off) = kSampTexel | texel;
             compact = true;
         } else {
             // A bounce ray that leaves the scene ends its path (most do).  Its innermost enclosing
@@ -1561,6 +1656,8 @@ RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned 
                 f[4 * i] = (uint32_t)p; f[4 * i + 1] = (uint32_t)(p >> 32);
                 f[4 * i + 2] = sc.sky_w[i]; f[4 * i + 3] = sc.sky_h[i];
             }
+            c[kCRcpW] = 1.0 / (double)fr.width; c[kCRcpH] = 1.0 / (double)fr.height;
+            c[kCScale] = fmax(fmax(fabs(fr.cam.eye[0]), fabs(fr.cam.eye[1])), fabs(fr.cam.eye[2])) + fabs(fr.cam.lens_z) + fabs(fr.cam.lens_w) + fabs(fr.cam.lens_h);
             RRT_LDS uint32_t* cv = (RRT_LDS uint32_t*)(c + kCCover);
             const uint64_t cp = (uint64_t)fr.cover;
             cv[0] = (uint32_t)cp; cv[1] = (uint32_t)(cp >> 32);
@@ -1630,13 +1727,18 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
             // ends in the sky.  Wave-uniform, so this is the whole iteration -- the same ray, the same texel, the same
             // sample word as process_ray's miss arm, without the hit path's registers around it.
             if (active) {
-                primary_ray(fr, lds, x, y, sample, &o, &d);
+                const RRT_GLOBAL uint8_t* tp;
+                if (!sky_texel_fast(fr, lds, x, y, sample, &tp)) {      // the texel is in doubt: the reference's chain
+                    primary_ray(fr, lds, x, y, sample, &o, &d);
+                    tp = sky_texel_ptr(sc, lds, d);
+                }
+                const uint32_t texel = (RRT_ABL & 1) ? 0u : ld_texel(tp);
                 if (sample == 0u) {
                     const size_t pixel = (size_t)y * fr.width + x;
                     if (d_ids) { d_ids[2 * pixel] = -1; d_ids[2 * pixel + 1] = -1; }
                     if (d_t) d_t[pixel] = 0.0;
                 }
-                at_off<uint32_t>(wk.samp32, path * 4u) = kSampTexel | sky_texel(sc, lds, d);
+                at_off<uint32_t>(wk.samp32, path * 4u) = kSampTexel | texel;
             }
             continue;
         }
