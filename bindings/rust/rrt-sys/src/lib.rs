@@ -41,6 +41,8 @@ pub struct rrt_settings {
     pub tile_rank: u32,
     pub tile_world: u32,
     pub batch_spp: u32,
+    pub tile_deal: u32,
+    pub reserved: u32,
 }
 
 #[repr(C)]
@@ -60,6 +62,9 @@ pub struct rrt_stats {
     pub level_rays: [u64; 4],
     pub cull_violations: u64,
     pub zero_mix_paths: u64,
+    pub sky_kernel_ms: f64,
+    pub heavy_tiles: u32,
+    pub sky_tiles: u32,
 }
 
 pub const RRT_TILE_W: u32 = 32;
@@ -129,6 +134,12 @@ extern "C" {
     pub fn rrt_gather_tiles(c: *mut rrt_comm, d_local: *const c_void, d_gathered: *mut c_void, width: u32, height: u32,
                             root: c_int, stream: *mut c_void) -> c_int;
     pub fn rrt_tile_slots(width: u32, height: u32, tile_world: u32) -> i64;
+    /// Bytes of a rank's compact tile buffer (with tile_deal: + its int32 slot -> tile table).
+    pub fn rrt_tile_buffer_bytes(width: u32, height: u32, tile_world: u32, tile_deal: u32) -> u64;
+    pub fn rrt_gather_tiles_dealt(c: *mut rrt_comm, d_local: *const c_void, d_gathered: *mut c_void, width: u32, height: u32,
+                                  root: c_int, stream: *mut c_void) -> c_int;
+    pub fn rrt_assemble_tiles_dealt(d_gathered: *const c_void, width: u32, height: u32, tile_world: u32,
+                                    d_rgb8: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn rrt_assemble_tiles(d_gathered: *const c_void, width: u32, height: u32, tile_world: u32,
                               d_rgb8: *mut c_void, stream: *mut c_void) -> c_int;
     pub fn rrt_trace_rays(s: *mut rrt_scene, rays: *const f64, n: i64, ent: *mut i32, tri: *mut i32,

@@ -310,7 +310,7 @@ impl RayTracer {
         let scene = Self::build(&world)?;
         let mut st = sys::rrt_settings {
             width: 0, height: 0, spp: 0, max_bounce: 0, seed: 0, prune_zero_mix: 0, tile_rank: 0, tile_world: 0,
-            batch_spp: 0,
+            batch_spp: 0, tile_deal: 0, reserved: 0,
         };
         unsafe { sys::rrt_default_settings(&mut st, w, h) };
         st.spp = self.settings.spp;

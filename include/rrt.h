@@ -67,7 +67,14 @@ typedef struct rrt_camera {
  *                AND of a column go to different ranks).  tile_world = 1 renders
  *                the whole frame.
  *   batch_spp    samples per pixel per wavefront batch; 0 = choose from the
- *                work-memory budget (rrt_set_work_budget). */
+ *                work-memory budget (rrt_set_work_budget).
+ *   tile_deal    (tile_world > 1) 1 = deal the tiles to the ranks BY COST instead of by position: every rank sorts
+ *                the image's tiles into [a mesh can be met, only spheres can, only sky] from the frame's tile bins
+ *                (each class in image order; the same list on every rank), and position p of that list is slot
+ *                p / tile_world of rank p % tile_world -- each rank gets its share of every class to within one
+ *                tile, so the ranks' frames cost the same.  The compact tile buffer then carries its slot -> tile
+ *                table behind the pixels (rrt_tile_buffer_bytes, rrt_gather_tiles_dealt, rrt_assemble_tiles_dealt).
+ *                0 = the positional map above.  The image does not depend on it. */
 typedef struct rrt_settings {
     uint32_t width;
     uint32_t height;
@@ -78,6 +85,8 @@ typedef struct rrt_settings {
     uint32_t tile_rank;
     uint32_t tile_world;
     uint32_t batch_spp;
+    uint32_t tile_deal;
+    uint32_t reserved;        /* 0 (keeps the struct free of hidden padding) */
 } rrt_settings;
 
 /* Filled by rrt_get_stats after a render. */
@@ -96,6 +105,9 @@ typedef struct rrt_stats {
     uint64_t level_rays[4];    /* rays cast at bounce level 0,1,2,3 (level 0 = primary)               */
     uint64_t cull_violations;  /* cull mode 2 only: entries the cull skipped but the exact test accepts (must be 0) */
     uint64_t zero_mix_paths;   /* primary hits whose reflection ray was cast with mix() == 0.0           */
+    double sky_kernel_ms;      /* summed hipEvent duration of the sky-only kernel launches (they run beside the primary kernel) */
+    uint32_t heavy_tiles;      /* tiles of this rank whose primary rays went through the wavefront kernels ...         */
+    uint32_t sky_tiles;        /* ... and tiles behind which there is only sky (0 / 0 for a frame without tile lists)  */
 } rrt_stats;
 
 #define RRT_TILE_W 32
@@ -313,10 +325,18 @@ uint32_t rrt_tile_skew(uint32_t width, uint32_t tile_world);
 /* Tiles each rank owns (padded to equal size so the gather is regular). */
 int64_t rrt_tile_slots(uint32_t width, uint32_t height, uint32_t tile_world);
 
+/* Bytes of a rank's compact tile buffer: rrt_tile_slots() x 768 pixels bytes, and with tile_deal the int32 slot ->
+ * tile table (image tile index ty * tiles_x + tx, -1 = padding) behind them. */
+uint64_t rrt_tile_buffer_bytes(uint32_t width, uint32_t height, uint32_t tile_world, uint32_t tile_deal);
+
 /* Root-side de-interleave after the RCCL gather: d_gathered is
  * [tile_world][slots][RRT_TILE_H][RRT_TILE_W][3]; writes row-major d_rgb8. */
 int rrt_assemble_tiles(const void* d_gathered, uint32_t width, uint32_t height, uint32_t tile_world, void* d_rgb8,
                        void* stream);
+/* The same for frames rendered with tile_deal = 1: d_gathered is [tile_world][rrt_tile_buffer_bytes(.., 1)]; every
+ * rank's buffer names its tiles itself, so the root needs nothing but the gathered bytes. */
+int rrt_assemble_tiles_dealt(const void* d_gathered, uint32_t width, uint32_t height, uint32_t tile_world, void* d_rgb8,
+                             void* stream);
 
 /* The frame's one exchange step for hosts that are not Python (no reference counterpart: the reference
  * is one process, src/tracer.rs:117-158).  One process per GPU; RCCL over xGMI inside the library,
@@ -336,6 +356,10 @@ int rrt_comm_init(int rank, int world, const void* id128, rrt_comm** out);
 void rrt_comm_destroy(rrt_comm* c);
 int rrt_gather_tiles(rrt_comm* c, const void* d_local, void* d_gathered, uint32_t width, uint32_t height, int root,
                      void* stream);
+/* ... of buffers rendered with tile_deal = 1 (rrt_tile_buffer_bytes(.., 1) bytes per rank); follow it with
+ * rrt_assemble_tiles_dealt. */
+int rrt_gather_tiles_dealt(rrt_comm* c, const void* d_local, void* d_gathered, uint32_t width, uint32_t height, int root,
+                           void* stream);
 
 /* The closest-hit loop of RayTracer::cast over world.entities
  * (src/tracer.rs:178-190 calling Entity::collide, common.rs:42) for caller

@@ -23,7 +23,7 @@ class Settings(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32),
                 ("max_bounce", C.c_uint32), ("seed", C.c_uint64),
                 ("prune_zero_mix", C.c_uint32), ("tile_rank", C.c_uint32),
-                ("tile_world", C.c_uint32), ("batch_spp", C.c_uint32)]
+                ("tile_world", C.c_uint32), ("batch_spp", C.c_uint32), ("tile_deal", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -33,7 +33,8 @@ class Stats(C.Structure):
                 ("primary_kernel_launches", C.c_uint32), ("bounce_kernel_launches", C.c_uint32),
                 ("n_batches", C.c_uint32), ("reserved", C.c_uint32),
                 ("level_rays", C.c_uint64 * 4), ("cull_violations", C.c_uint64),
-                ("zero_mix_paths", C.c_uint64)]
+                ("zero_mix_paths", C.c_uint64), ("sky_kernel_ms", C.c_double),
+                ("heavy_tiles", C.c_uint32), ("sky_tiles", C.c_uint32)]
 
 
 # every symbol include/rrt.h and include/rrt_host.h declare
@@ -44,7 +45,7 @@ EXPORTS = [
     "rrt_set_directional_light", "rrt_add_directional_light", "rrt_set_ambient", "rrt_add_point_light", "rrt_set_shadow_mode", "rrt_translate_entity",
     "rrt_occluded_rays", "rrt_set_work_budget", "rrt_set_cull_mode", "rrt_set_timing",
     "rrt_scene_commit",
-    "rrt_render", "rrt_alloc_host_pinned", "rrt_free_host_pinned", "rrt_release_stream", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_tile_skew", "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_gather_tiles", "rrt_assemble_tiles",
+    "rrt_render", "rrt_alloc_host_pinned", "rrt_free_host_pinned", "rrt_release_stream", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_tile_buffer_bytes", "rrt_tile_skew", "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_gather_tiles", "rrt_gather_tiles_dealt", "rrt_assemble_tiles", "rrt_assemble_tiles_dealt",
     "rrt_trace_rays", "rrt_cast_rays", "rrt_get_stats", "rrt_mesh_tree_sizes",
     "rrt_mesh_tree_export", "rrt_cover_mask", "rrt_selftest_math", "rrt_philox4x32_10",
     "rrt_host_load_model", "rrt_host_add_model", "rrt_host_load_model_ex", "rrt_host_add_model_ex", "rrt_host_load_png_rgb8",
@@ -116,6 +117,10 @@ def _load():
     L.rrt_tile_slots.argtypes = [u32, u32, u32]
     L.rrt_tile_slots.restype = i64
     L.rrt_assemble_tiles.argtypes = [vp, u32, u32, u32, vp, vp]
+    L.rrt_assemble_tiles_dealt.argtypes = [vp, u32, u32, u32, vp, vp]
+    L.rrt_gather_tiles_dealt.argtypes = [vp, vp, vp, u32, u32, i32, vp]
+    L.rrt_tile_buffer_bytes.argtypes = [u32, u32, u32, u32]
+    L.rrt_tile_buffer_bytes.restype = u64
     L.rrt_trace_rays.argtypes = [vp, vp, i64, vp, vp, vp, vp, vp]
     L.rrt_cast_rays.argtypes = [vp, vp, i64, u32, u32, vp]
     L.rrt_get_stats.argtypes = [vp, C.POINTER(Stats)]

@@ -97,13 +97,17 @@ struct SkyFace {
 
 struct TimedLaunch {
     hipEvent_t a = nullptr, b = nullptr;
-    bool primary = false;
+    int kind = 0;            // 0 = primary kernel, 1 = bounce levels, 2 = sky kernel
     uint32_t launches = 1;   // kernel launches between a and b
 };
 
 struct WorkSet {
     hipStream_t stream = nullptr;
-    DevBuf w_q[2], w_rec, w_samp, w_samp32, w_accum, w_zero, w_bins;   // w_zero: what a frame starts from zero, see zero_layout
+    DevBuf w_q[2], w_rec, w_samp, w_samp32, w_accum, w_zero, w_bins, w_lists;   // w_zero: what a frame starts from zero, see zero_layout
+    hipStream_t side = nullptr;                 // the sky kernel runs here, beside the wavefront kernels
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint32_t spp = 0;                           // of the last frame (rrt_get_stats: paths of a dealt frame = device count x spp)
+    bool dealt = false, lists = false;
     // timing and counters of the last frame rendered with this set
     std::vector<TimedLaunch> timed;
     size_t timed_used = 0;
@@ -121,6 +125,9 @@ struct WorkSet {
         }
         if (ev_begin) (void)hipEventDestroy(ev_begin);
         if (ev_end) (void)hipEventDestroy(ev_end);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
     }
 };
 
@@ -526,7 +533,9 @@ struct FramePlan {
     uint32_t n_batches = 0;
     uint64_t cap = 0;  // paths per batch
     uint64_t valid_px = 0;
-    bool want_bins = false;   // this frame fills DFrame::tile_bins
+    bool want_bins = false;   // this frame fills DFrame::tile_bins from the scene
+    bool want_lists = false;  // ... and the tile lists (always with the bins; a dealt frame has them even without)
+    bool dealt = false;       // rrt_settings::tile_deal: tiles dealt to the ranks by cost class
 };
 
 size_t bytes_per_path(uint32_t levels) {
@@ -629,22 +638,32 @@ uint64_t cover_stride(uint32_t width) { return ((uint64_t)(width + rrt::kCoverCe
 uint64_t cover_bytes(const rrt::DFrame& fr) { return (uint64_t)fr.n_cover * fr.cover_bytes; }
 // What every frame starts from zero sits in ONE block, so that it is one memset (each is a ~4 us kernel in the frame's
 // launch chain): the statistics, the queue counters (zeroed again in front of every further batch) and the coverage masks.
-constexpr uint64_t kStatsBytes = 8 * 8, kQCountBytes = 2 * (rrt::kMaxLevels + 1) * 4;
+constexpr uint64_t kStatsBytes = 8 * 8, kQCountBytes = 2 * (rrt::kMaxLevels + 1) * 4, kListNBytes = 16;
 uint64_t zero_bytes(const rrt::DFrame& fr) { return 256 + cover_bytes(fr); }
-static_assert(kStatsBytes + kQCountBytes <= 256, "statistics and queue counters share the block's first 256 bytes");
+static_assert(kStatsBytes + kQCountBytes + kListNBytes <= 256, "statistics, queue counters and list counts share the block's first 256 bytes");
 void zero_layout(unsigned char* base, FramePlan& pl, rrt::DWork* wk) {
     wk->stats = (unsigned long long*)base;
-    wk->q_count = (uint32_t*)(base + kStatsBytes);
+    wk->q_count = (unsigned long long*)(base + kStatsBytes);
+    pl.fr.list_n = pl.want_lists ? (const uint32_t*)(base + kStatsBytes + kQCountBytes) : nullptr;
     pl.fr.cover = pl.fr.n_cover ? base + 256 : nullptr;
 }
 uint64_t bins_bytes(const rrt::DFrame& fr, bool want) { return want ? (uint64_t)fr.tiles_x * fr.tiles_y * 8 : 0; }
+uint64_t lists_bytes(const rrt::DFrame& fr, bool want) { return want ? (uint64_t)fr.n_slots * 8 : 0; }     // order, then slot_tile
+void lists_layout(unsigned char* base, FramePlan& pl) {
+    pl.fr.order = pl.want_lists ? (const int32_t*)base : nullptr;
+    pl.fr.slot_tile = pl.want_lists && pl.dealt ? (const int32_t*)base + pl.fr.n_slots : nullptr;
+}
 
 int ensure_work(WorkSet* s, FramePlan& pl, rrt::DWork* wk) {
     const uint64_t P = pl.cap;
     HIP_TRY(s->w_zero.ensure(zero_bytes(pl.fr)));
     zero_layout((unsigned char*)s->w_zero.p, pl, wk);
-    if (pl.want_bins) HIP_TRY(s->w_bins.ensure(bins_bytes(pl.fr, true)));
-    pl.fr.tile_bins = pl.want_bins ? s->w_bins.as<uint64_t>() : nullptr;
+    if (pl.want_lists) {
+        HIP_TRY(s->w_bins.ensure(bins_bytes(pl.fr, true)));
+        HIP_TRY(s->w_lists.ensure(lists_bytes(pl.fr, true)));
+    }
+    pl.fr.tile_bins = pl.want_lists ? s->w_bins.as<uint64_t>() : nullptr;
+    lists_layout((unsigned char*)s->w_lists.p, pl);
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(s->w_q[i].ensure(P * rrt::kRecDoubles * 8));
         wk->q[i] = s->w_q[i].as<double>();
@@ -669,7 +688,7 @@ uint64_t carve_bytes(const FramePlan& pl) {
     const uint64_t P = pl.cap;
     const uint64_t parts[] = {zero_bytes(pl.fr), P * rrt::kRecDoubles * 8, P * rrt::kRecDoubles * 8,
                               P * rrt::kRecDoubles * 8 * pl.levels, P * 3 * 8, P * 4, (uint64_t)pl.fr.npx_local * 3 * 8,
-                              bins_bytes(pl.fr, pl.want_bins)};
+                              bins_bytes(pl.fr, pl.want_lists), lists_bytes(pl.fr, pl.want_lists)};
     uint64_t total = 0;
     for (uint64_t b : parts) total += (b + kCarveAlign - 1) / kCarveAlign * kCarveAlign;
     return total;
@@ -691,7 +710,8 @@ int carve_work(unsigned char* base, uint64_t bytes, FramePlan& pl, rrt::DWork* w
     wk->samp = (double*)take(P * 3 * 8);
     wk->samp32 = (uint32_t*)take(P * 4);
     wk->accum = (double*)take((uint64_t)pl.fr.npx_local * 3 * 8);
-    pl.fr.tile_bins = pl.want_bins ? (const uint64_t*)take(bins_bytes(pl.fr, true)) : nullptr;
+    pl.fr.tile_bins = pl.want_lists ? (const uint64_t*)take(bins_bytes(pl.fr, true)) : nullptr;
+    lists_layout(take(lists_bytes(pl.fr, pl.want_lists)), pl);
     wk->cap = P;
     return RRT_OK;
 }
@@ -730,11 +750,12 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     // Tile bins (DFrame::tile_bins) go with them: which entities of a small scene a tile's primary rays can meet.
     uint64_t mask_bytes = 0;
     uint32_t n_cover = 0;
-    bool want_bins = false;
+    bool want_bins = false, want_lists = false;
     const auto count_masks = [&]() {      // needs the committed scene
         n_cover = 0;
         mask_bytes = 0;
         want_bins = false;
+        want_lists = false;
         static const bool bins_on = [] { const char* e = getenv("RRT_BINS"); return !e || atoi(e) != 0; }();   // A/B knob
         if (cam && st && st->width && st->height && !s->dirty && s->cull_mode != 0 && cam->lens_z > 0.0 &&
             cam->lens_w > 0.0 && cam->lens_h > 0.0 && std::isfinite(cam->lens_z + cam->lens_w + cam->lens_h + cam->eye[0] + cam->eye[1] + cam->eye[2])) {
@@ -745,7 +766,12 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
             if (NOALLOC && mask_bytes > rrt::kScratchBytes / 8) { n_cover = 0; mask_bytes = 0; }     // a huge image: leave the scratch to the paths
             // bins are worth their launch once the frame has some paths (a 640x480 frame at 1 spp is four launches long)
             want_bins = bins_on && s->dscene.lds_ents != 0 && s->ents.size() >= 2 && (uint64_t)st->width * st->height * st->spp >= (1u << 20);
-            if (want_bins) mask_bytes += (uint64_t)((st->width + 31) / 32) * ((st->height + 7) / 8) * 8 + kCarveAlign;
+        }
+        // a dealt frame (rrt_settings::tile_deal) always carries the tile lists: they hold its slot -> tile table
+        want_lists = want_bins || (st && st->tile_deal != 0 && st->tile_world > 1);
+        if (want_lists && st && st->width && st->height) {
+            const uint64_t n_img = (uint64_t)((st->width + 31) / 32) * ((st->height + 7) / 8);
+            mask_bytes += n_img * 8 + (n_img / (st->tile_world ? st->tile_world : 1) + 1) * 8 + 2 * kCarveAlign;
         }
     };
     if (NOALLOC) count_masks();           // (an uncommitted scene is refused below)
@@ -772,6 +798,8 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         if (e != 0 || !base) return fail(RRT_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString((hipError_t)e));
         pl.fr.n_cover = n_cover;
         pl.want_bins = want_bins;
+        pl.want_lists = want_lists;
+        pl.dealt = st->tile_deal != 0 && st->tile_world > 1;
         rc = carve_work(base, rrt::kScratchBytes, pl, &wk);
         if (rc) return rc;
     } else {
@@ -780,6 +808,8 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         count_masks();
         pl.fr.n_cover = n_cover;
         pl.want_bins = want_bins;
+        pl.want_lists = want_lists;
+        pl.dealt = st->tile_deal != 0 && st->tile_world > 1;
         rc = work_set_for(s, stream, &ws);
         if (rc) return rc;
         rc = ensure_work(ws, pl, &wk);
@@ -800,17 +830,57 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         for (uint32_t k = 0; k < fr.n_cover; ++k)
             rrt::launch_cover(s->dmeshes[(size_t)s->cover[k].first], s->cover[k].second, fr, k, stream);
     }
-    if (fr.tile_bins) rrt::launch_bins(s->dscene, fr, stream);
+    fr.chunks_per_block = rrt::primary_chunks_per_block();
+    if (pl.want_bins) rrt::launch_bins(s->dscene, fr, stream);
+    else if (pl.want_lists) HIP_TRY(hipMemsetAsync(const_cast<uint64_t*>(fr.tile_bins), 0xff, bins_bytes(fr, true), stream));   // dealt, no bins: every tile "can meet everything"
+    if (pl.want_lists) {
+        uint64_t mesh_mask = 0;
+        for (size_t e = 0; e < s->ents.size() && e < 64; ++e)
+            if ((s->ents[e].kind & ~rrt::kEntityMember) == 1) mesh_mask |= 1ull << e;
+        if (!pl.want_bins) mesh_mask = ~0ull;
+        // cull mode 2 (verify): every tile goes through the wavefront kernels, which check the bins
+        rrt::launch_lists(fr, mesh_mask, pl.dealt, s->cull_mode != 1 || !pl.want_bins, stream);
+    }
+    // The sky-only tiles run beside the wavefront kernels on a stream of their own (RRT_SKY_FORK=0, and the entry
+    // point that allocates nothing: in front of them on the same stream).
+    static const bool fork_on = [] { const char* e = getenv("RRT_SKY_FORK"); return !e || atoi(e) != 0; }();
+    const bool fork = pl.want_lists && !NOALLOC && fork_on;
+    if (fork && !ws->side) {
+        HIP_TRY(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming));
+    }
+    ws->spp = st->spp;
+    ws->dealt = pl.dealt;
+    ws->lists = pl.want_lists;
     for (uint32_t b = 0; b < pl.n_batches; ++b) {
         fr.s0 = b * pl.batch_spp;
         fr.ns = std::min(pl.batch_spp, st->spp - fr.s0);
         fr.pack_log2 = sample_pack_log2(fr.ns);
         if (b > 0) HIP_TRY(hipMemsetAsync(wk.q_count, 0, kQCountBytes, stream));
         TimedLaunch* tl = nullptr;
+        if (pl.want_lists) {
+            // (the sky kernel writes sample words the previous batch's accumulate pass reads: it starts behind it)
+            hipStream_t ss = fork ? ws->side : stream;
+            if (fork) {
+                HIP_TRY(hipEventRecord(ws->ev_fork, stream));
+                HIP_TRY(hipStreamWaitEvent(ss, ws->ev_fork, 0));
+            }
+            if (timed_kernels) {
+                rc = timed_slot(ws, &tl);
+                if (rc) return rc;
+                tl->kind = 2;
+                tl->launches = 1;
+                HIP_TRY(hipEventRecord(tl->a, ss));
+            }
+            rrt::launch_sky(s->dscene, wk, fr, (int32_t*)d_ids, (double*)d_t, ss);
+            if (timed_kernels) HIP_TRY(hipEventRecord(tl->b, ss));
+            if (fork) HIP_TRY(hipEventRecord(ws->ev_join, ss));
+        }
         if (timed_kernels) {
             rc = timed_slot(ws, &tl);
             if (rc) return rc;
-            tl->primary = true;
+            tl->kind = 0;
             tl->launches = 1;
             HIP_TRY(hipEventRecord(tl->a, stream));
         }
@@ -821,13 +891,14 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
             // launches costs ~3 us of idle GPU: ten events a frame were 1.5 % of it)
             rc = timed_slot(ws, &tl);
             if (rc) return rc;
-            tl->primary = false;
+            tl->kind = 1;
             tl->launches = st->max_bounce + 1;
             HIP_TRY(hipEventRecord(tl->a, stream));
         }
         for (uint32_t bounce = 1; bounce <= st->max_bounce + 1; ++bounce)
             rrt::launch_bounce(s->dscene, wk, fr, bounce, stream);
         if (timed_kernels) HIP_TRY(hipEventRecord(tl->b, stream));
+        if (fork) HIP_TRY(hipStreamWaitEvent(stream, ws->ev_join, 0));
         const bool last = b + 1 == pl.n_batches;
         if (last && bands && bands->n_bands > 1 && d_rgb8 && st->tile_world == 1) {
             for (uint32_t k = 0; k < bands->n_bands; ++k) {
@@ -844,6 +915,9 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
             rrt::launch_accumulate(wk, fr, last, (uint8_t*)d_rgb8, (double*)d_color, stream);   // the last one resolves
         }
     }
+    if (pl.dealt && d_rgb8)       // the slot -> tile table travels behind the pixels (rrt_assemble_tiles_dealt reads it)
+        HIP_TRY(hipMemcpyAsync((uint8_t*)d_rgb8 + (size_t)fr.n_slots * RRT_TILE_W * RRT_TILE_H * 3, fr.slot_tile, (size_t)fr.n_slots * 4,
+                               hipMemcpyDeviceToDevice, stream));
     if (timed) HIP_TRY(hipEventRecord(ws->ev_end, stream));
     HIP_TRY(hipGetLastError());
     s->last = ws;
@@ -890,6 +964,11 @@ void rrt_default_settings(rrt_settings* st, uint32_t w, uint32_t h) {
     st->spp = 1;
     st->max_bounce = 2;
     st->tile_world = 1;
+}
+
+uint64_t rrt_tile_buffer_bytes(uint32_t width, uint32_t height, uint32_t tile_world, uint32_t tile_deal) {
+    const uint64_t slots = (uint64_t)rrt_tile_slots(width, height, tile_world);
+    return slots * RRT_TILE_W * RRT_TILE_H * 3 + (tile_deal && tile_world > 1 ? slots * 4 : 0);
 }
 
 rrt_scene* rrt_scene_create(void) {
@@ -1319,6 +1398,16 @@ int rrt_assemble_tiles(const void* d_gathered, uint32_t width, uint32_t height, 
     return RRT_OK;
 }
 
+int rrt_assemble_tiles_dealt(const void* d_gathered, uint32_t width, uint32_t height, uint32_t tile_world, void* d_rgb8,
+                             void* stream) {
+    if (!d_gathered || !d_rgb8 || tile_world == 0 || width == 0 || height == 0)
+        return fail(RRT_E_INVALID, "bad argument");
+    if (tile_world == 1) return fail(RRT_E_INVALID, "a single rank's frame is row-major already (tile_deal needs tile_world > 1)");
+    rrt::launch_assemble_dealt((const uint8_t*)d_gathered, width, height, tile_world, (uint8_t*)d_rgb8, stream);
+    HIP_TRY(hipGetLastError());
+    return RRT_OK;
+}
+
 static int ray_query(rrt_scene* s, const double* rays, int64_t n, bool cast, uint32_t max_bounce, uint32_t prune,
                      int32_t* ent, int32_t* tri, double* t, double* pos, double* nrm, double* color) {
     if (!s || !rays || n < 0) return fail(RRT_E_INVALID, "bad argument");
@@ -1406,20 +1495,34 @@ int rrt_get_stats(const rrt_scene* cs, rrt_stats* out) try {
         HIP_TRY(hipDeviceSynchronize());   // an untimed (no-alloc) frame: wait for its stream the blunt way
     }
     ws->stats.gpu_ms = ms;
-    double prim = 0.0, bnc = 0.0;
+    double prim = 0.0, bnc = 0.0, sky = 0.0;
     uint32_t nprim = 0, nbnc = 0;
     for (size_t i = 0; i < ws->timed_used; ++i) {
         float k = 0.f;
         HIP_TRY(hipEventElapsedTime(&k, ws->timed[i].a, ws->timed[i].b));
-        if (ws->timed[i].primary) { prim += k; nprim += ws->timed[i].launches; }
-        else { bnc += k; nbnc += ws->timed[i].launches; }
+        if (ws->timed[i].kind == 0) { prim += k; nprim += ws->timed[i].launches; }
+        else if (ws->timed[i].kind == 1) { bnc += k; nbnc += ws->timed[i].launches; }
+        else sky += k;
     }
+    ws->stats.sky_kernel_ms = sky;
     ws->stats.primary_kernel_ms = prim;
     ws->stats.bounce_kernel_ms = bnc;
     ws->stats.primary_kernel_launches = nprim;
     ws->stats.bounce_kernel_launches = nbnc;
-    unsigned long long dev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dev[32] = {};        // the zero block's head: statistics, queue counters, list counts
+    static_assert(sizeof(dev) == 256, "head of the zero block");
     HIP_TRY(hipMemcpy(dev, ws->stats_src, sizeof(dev), hipMemcpyDeviceToHost));
+    ws->stats.heavy_tiles = ws->stats.sky_tiles = 0;
+    if (ws->lists) {
+        uint32_t ln[4];
+        std::memcpy(ln, (const unsigned char*)dev + kStatsBytes + kQCountBytes, sizeof(ln));
+        ws->stats.heavy_tiles = ln[0];
+        ws->stats.sky_tiles = ln[1] - ln[0];
+        if (ws->dealt) {                     // which tiles a rank owns is decided on the device: so is its pixel count
+            ws->stats.paths = (uint64_t)ln[2] * ws->spp;
+            ws->stats.primary_rays = ws->stats.paths;
+        }
+    }
     ws->stats.rays_traced = ws->stats.primary_rays + dev[0];
     ws->stats.traversal_overflow = dev[1];
     ws->stats.cull_violations = dev[2];

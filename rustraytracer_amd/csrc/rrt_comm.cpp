@@ -125,14 +125,14 @@ void rrt_comm_destroy(rrt_comm* c) {
     delete c;
 }
 
-int rrt_gather_tiles(rrt_comm* c, const void* d_local, void* d_gathered, uint32_t width, uint32_t height, int root,
-                     void* stream_v) {
+static int gather_tiles(rrt_comm* c, const void* d_local, void* d_gathered, uint32_t width, uint32_t height, int root,
+                        void* stream_v, uint32_t dealt) {
     if (!c || !d_local || width == 0 || height == 0 || root < -1 || root >= c->world) return cfail(RRT_E_INVALID, "bad argument");
     const bool receives = root < 0 || root == c->rank;
     if (receives && !d_gathered) return cfail(RRT_E_INVALID, "the receiving rank needs d_gathered");
     Rccl* R = rccl();
     hipStream_t stream = (hipStream_t)stream_v;
-    const size_t bytes = (size_t)rrt_tile_slots(width, height, (uint32_t)c->world) * RRT_TILE_W * RRT_TILE_H * 3;
+    const size_t bytes = (size_t)rrt_tile_buffer_bytes(width, height, (uint32_t)c->world, dealt);
     if (root < 0) {
         NCCL_TRY(R->AllGather(d_local, d_gathered, bytes, ncclUint8, c->comm, stream));
         return RRT_OK;
@@ -163,6 +163,15 @@ int rrt_gather_tiles(rrt_comm* c, const void* d_local, void* d_gathered, uint32_
     if (first != ncclSuccess) return cfail(RRT_E_HIP, std::string(where) + ": " + R->GetErrorString(first));
     if (end != ncclSuccess) return cfail(RRT_E_HIP, std::string("ncclGroupEnd: ") + R->GetErrorString(end));
     return RRT_OK;
+}
+
+int rrt_gather_tiles(rrt_comm* c, const void* d_local, void* d_gathered, uint32_t width, uint32_t height, int root,
+                     void* stream) {
+    return gather_tiles(c, d_local, d_gathered, width, height, root, stream, 0);
+}
+int rrt_gather_tiles_dealt(rrt_comm* c, const void* d_local, void* d_gathered, uint32_t width, uint32_t height, int root,
+                           void* stream) {
+    return gather_tiles(c, d_local, d_gathered, width, height, root, stream, 1);
 }
 
 }  // extern "C"

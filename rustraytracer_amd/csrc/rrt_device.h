@@ -224,7 +224,7 @@ constexpr int32_t kTopLink = -2;         // DNodeI::axis of a top-array entry th
 constexpr int kRecDoubles = 7;
 struct DWork {
     double* q[2];        // [P][7]          ray queues (read / written alternately by the bounce levels)
-    uint32_t* q_count;   // [2][kMaxLevels + 1] queue entries per bounce level: live rays (from the front), dead rays (from the back)
+    unsigned long long* q_count;   // [kMaxLevels + 1] queue entries per bounce level: low word = live rays (from the front), high word = dead rays (from the back)
     double* rec;         // [levels][P][7]  shading records of the continuing casts
     double* samp;        // [P][3]          finished per-sample colour ...
     uint32_t* samp32;    // [P]             ... unless this says kSampTexel | sky texel (a primary ray that ended in the sky)
@@ -253,6 +253,17 @@ struct DFrame {
     // grid), bit e clear = no primary ray through that tile can be answered by entity e (a sphere whose projected
     // bounds miss the tile, a mesh whose coverage mask is clear over it).  Scenes of at most 64 entities.
     const uint64_t* tile_bins;
+    // Tile lists of this frame (k_lists; present whenever tile_bins is).  `order`: the rank's tile slots in processing
+    // order -- first the list_n[0] slots whose tile a primary ray can meet an entity in ("heavy": k_wave_primary), then,
+    // up to list_n[1], the slots behind which there is only sky (k_sky); padding slots last.  `slot_tile` (dealt mode,
+    // rrt_settings::tile_deal): the image tile (ty * tiles_x + tx) of slot j, -1 = padding -- the tiles are dealt to
+    // the ranks by cost class from the bins instead of by position, see k_lists; nullptr = the arithmetic map
+    // (tile_skew below).  list_n = {heavy slots, valid slots, valid pixels of this rank, -}.
+    const int32_t* slot_tile;
+    const int32_t* order;
+    const uint32_t* list_n;
+    uint32_t chunks_per_block;   // 256-path chunks a persistent block of the primary kernel is sized for
+    uint32_t pad_;
 };
 
 // Tile t (t % tile_world = owner, t / tile_world = slot) is the tile in row ty = t / tiles_x of the image, column
@@ -283,6 +294,13 @@ void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint
 void launch_cover(const DMesh& mesh, int32_t n_entries, const DFrame& fr, uint32_t slot, void* stream);
 // Fills fr.tile_bins from the scene's spheres and the frame's coverage masks (after launch_cover).
 void launch_bins(const DScene& sc, const DFrame& fr, void* stream);
+// Fills fr.order / fr.list_n (and fr.slot_tile when `dealt`) from fr.tile_bins; mesh_mask = entity bits that are meshes.
+void launch_lists(const DFrame& fr, uint64_t mesh_mask, bool dealt, bool all_heavy, void* stream);
+uint32_t primary_chunks_per_block();
+// The sky-only slots of the batch (fr.order[list_n[0] .. list_n[1])): texel words into wk.samp32, AOVs of sample 0.
+void launch_sky(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream);
+// Dealt mode: [world][slots x 768 B pixels, slots x int32 tile table] -> row-major frame.
+void launch_assemble_dealt(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream);
 void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream);
 void launch_trace_rays(const DScene& sc, const double* d_rays, int64_t n, int32_t* ent, int32_t* tri, double* t,
                        double* pos, double* nrm, unsigned long long* stats, void* stream);

@@ -47,6 +47,9 @@ namespace {
 #ifndef RRT_XCD_ORDER
 #define RRT_XCD_ORDER 1
 #endif
+#ifndef RRT_EXP_NOATOMIC
+#define RRT_EXP_NOATOMIC 0
+#endif
 #if RRT_PROBE
 __device__ unsigned long long g_phase[32];
 #if RRT_PROBE == 2      // timing only: the event counters' atomics would be what is timed
@@ -1206,18 +1209,23 @@ RRT_DEV void ld_rec(double* level_base, uint32_t idx, V3* A, V3* Pm, double* mix
     *Pm = mk(b.y, c.x, c.y);
 }
 
-// Wave-aggregated queue append: one atomic per wave.
-RRT_DEV uint32_t queue_slot(uint32_t* counter, bool want) {
-    const unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return 0u;
+// Wave-aggregated queue append: ONE atomic per wave for both ends of the queue.  A level's counter is 64 bits -- live
+// entries in the low word, dead entries in the high word (a batch holds fewer than 2^32 paths, so the low word never
+// carries).  Every wave of the chip adds to the same address, and such atomics are performed one after the other at
+// the memory side: with one atomic each for the live end, the dead end and a statistics counter the primary kernel of
+// the 1080p/64spp frame spent a third of its time (1.25 of 3.64 ms) queueing for them.
+RRT_DEV void queue_slots(unsigned long long* counter, bool live, bool dead, uint32_t* slot_live, uint32_t* slot_dead) {
+    const unsigned long long ml = __ballot(live), md = __ballot(dead);
+    *slot_live = 0u; *slot_dead = 0u;
+    if ((ml | md) == 0ull) return;
     const uint32_t lane = __lane_id();
-    const uint32_t n = (uint32_t)__popcll(mask);
-    const uint32_t before = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, n);
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    return base + before;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int leader = __ffsll((long long)(ml | md)) - 1;
+    unsigned long long base = 0ull;
+    if ((int)lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(ml) | ((unsigned long long)__popcll(md) << 32));
+    const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, leader, 64), bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader, 64);
+    *slot_live = blo + (uint32_t)__popcll(ml & below);
+    *slot_dead = bhi + (uint32_t)__popcll(md & below);
 }
 
 // tracer.rs:84-110, 126-131 with the sub-pixel jitter extension.
@@ -1383,11 +1391,26 @@ RRT_DEV void path_decode(const DFrame& fr, uint32_t path, uint32_t* s_local, uin
     *pp = (slot << 8) | ((sc & sm) << (8u - p)) | (t >> p);
 }
 
-RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y) {
-    const uint32_t slot = lp >> 8, in = lp & 255u;
+// Where tile slot `slot` of this rank lies in the tile grid; false = a padding slot.
+RRT_DEV bool slot_pos(const DFrame& fr, uint32_t slot, uint32_t* tx, uint32_t* ty) {
+    if (fr.slot_tile) {                                   // dealt mode: the table k_lists wrote
+        const int32_t p = fr.slot_tile[slot];
+        if (p < 0) return false;
+        *ty = (uint32_t)p / fr.tiles_x;
+        *tx = (uint32_t)p - *ty * fr.tiles_x;
+        return true;
+    }
     const uint32_t tile = slot * fr.tile_world + fr.tile_rank;
     if (tile >= fr.tiles_x * fr.tiles_y) return false;
-    const uint32_t ty = tile / fr.tiles_x, tx = (tile - ty * fr.tiles_x + fr.tile_skew * ty) % fr.tiles_x;
+    *ty = tile / fr.tiles_x;
+    *tx = tile - *ty * fr.tiles_x;
+    if (fr.tile_skew) *tx = (*tx + fr.tile_skew * *ty) % fr.tiles_x;
+    return true;
+}
+RRT_DEV bool local_pixel(const DFrame& fr, uint32_t lp, uint32_t* x, uint32_t* y) {
+    const uint32_t slot = lp >> 8, in = lp & 255u;
+    uint32_t tx, ty;
+    if (!slot_pos(fr, slot, &tx, &ty)) return false;
     *x = tx * RRT_TILE_W + (in & 31u);
     *y = ty * RRT_TILE_H + (in >> 5);
     return *x < fr.width && *y < fr.height;
@@ -1425,8 +1448,12 @@ RRT_DEV uint32_t cover_bits(LDS lds, uint32_t x, uint32_t y) {
 // 10.7 k cycles for an all-dead unit against 43 k for one with live rays in it.
 RRT_DEV void enqueue_continuation(const DWork& wk, uint32_t bounce, bool cont, bool zero_mix, V3 ro, V3 rd, uint32_t path,
                                   int32_t medium) {
-    const uint32_t slot_live = queue_slot(&wk.q_count[bounce + 1], cont && !zero_mix);
-    const uint32_t slot_dead = queue_slot(&wk.q_count[kMaxLevels + 1 + bounce + 1], cont && zero_mix);
+#if RRT_EXP_NOATOMIC       // timing experiment only (results are wrong): no queue counters at all, entry = path
+    const uint32_t slot_live = path, slot_dead = (uint32_t)wk.cap - 1u - path;
+#else
+    uint32_t slot_live, slot_dead;
+    queue_slots(&wk.q_count[bounce + 1], cont && !zero_mix, cont && zero_mix, &slot_live, &slot_dead);
+#endif
     if (cont) {
         // queue entry {o.xyz, d.xyz, (path, medium)}
         double* q = wk.q[(bounce + 1) & 1];
@@ -1555,10 +1582,8 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
             }
         }
     }
-    if (PRIMARY) {   // stats[3]: primary hits that continue with a dead (mix 0.0) ray -- one atomic per wave that has any
-        const unsigned long long zm = __ballot(cont && zero_mix);
-        if (zm != 0ull && (int)__lane_id() == __ffsll((long long)zm) - 1) atomicAdd(&wk.stats[3], (unsigned long long)__popcll(zm));
-    }
+    // (stats[3], the primary hits that continue with a dead (mix 0.0) ray, is the dead end of the level-1 queue: the
+    // bounce kernel adds it up from the counter)
     if (!PRIMARY && next) {
         next->o = ro; next->d = rd; next->medium = medium; next->cont = cont; next->zero_mix = zero_mix;
         return;
@@ -1572,6 +1597,35 @@ __host__ __device__ inline uint32_t lds_layout_bytes(const DScene& sc) {
     return (uint32_t)sc.lds_nodes * (uint32_t)sizeof(DNodeI) +
            (sc.lds_ents ? (uint32_t)sc.n_ents * (uint32_t)kEntRec * 4u : 0u) +
            (uint32_t)sc.lds_mats * (uint32_t)sizeof(DMaterial) + 256u * 8u + (uint32_t)kCDoubles * 8u;
+}
+
+// The per-frame constants block (kC*) at `at`; thread 0 writes it, the caller's barrier publishes it.
+RRT_DEV RRT_LDS double* stage_consts(const DScene& sc, const DFrame& fr, unsigned char* at) {
+    RRT_LDS double* c = (RRT_LDS double*)at;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            c[kCLightDir + a] = sc.light_dir[a];
+            c[kCLightColor + a] = sc.light_color[a];
+            c[kCEye + a] = fr.cam.eye[a];
+        }
+        c[kCIntensity] = sc.light_intensity; c[kCAmbient] = sc.ambient;
+        c[kCLensZ] = fr.cam.lens_z; c[kCLensW] = fr.cam.lens_w; c[kCLensH] = fr.cam.lens_h;
+        RRT_LDS uint32_t* f = (RRT_LDS uint32_t*)(c + kCFaces);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const uint64_t p = (uint64_t)sc.sky[i];
+            f[4 * i] = (uint32_t)p; f[4 * i + 1] = (uint32_t)(p >> 32);
+            f[4 * i + 2] = sc.sky_w[i]; f[4 * i + 3] = sc.sky_h[i];
+        }
+        c[kCRcpW] = 1.0 / (double)fr.width; c[kCRcpH] = 1.0 / (double)fr.height;
+        c[kCScale] = fmax(fmax(fabs(fr.cam.eye[0]), fabs(fr.cam.eye[1])), fabs(fr.cam.eye[2])) + fabs(fr.cam.lens_z) + fabs(fr.cam.lens_w) + fabs(fr.cam.lens_h);
+        RRT_LDS uint32_t* cv = (RRT_LDS uint32_t*)(c + kCCover);
+        const uint64_t cp = (uint64_t)fr.cover;
+        cv[0] = (uint32_t)cp; cv[1] = (uint32_t)(cp >> 32);
+        cv[2] = fr.cover ? fr.n_cover : 0u; cv[3] = fr.cover_stride; cv[4] = fr.cover_bytes; cv[5] = 0u;
+    }
+    return c;
 }
 
 // Fills the block's LDS (all threads; ends with a barrier): the staged descent arrays (DScene::st_*) and,
@@ -1638,33 +1692,7 @@ RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned 
         st.by255 = tab;
         off += 256u * 8u;
     }
-    {
-        RRT_LDS double* c = (RRT_LDS double*)(smem + off);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                c[kCLightDir + a] = sc.light_dir[a];
-                c[kCLightColor + a] = sc.light_color[a];
-                c[kCEye + a] = fr.cam.eye[a];
-            }
-            c[kCIntensity] = sc.light_intensity; c[kCAmbient] = sc.ambient;
-            c[kCLensZ] = fr.cam.lens_z; c[kCLensW] = fr.cam.lens_w; c[kCLensH] = fr.cam.lens_h;
-            RRT_LDS uint32_t* f = (RRT_LDS uint32_t*)(c + kCFaces);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const uint64_t p = (uint64_t)sc.sky[i];
-                f[4 * i] = (uint32_t)p; f[4 * i + 1] = (uint32_t)(p >> 32);
-                f[4 * i + 2] = sc.sky_w[i]; f[4 * i + 3] = sc.sky_h[i];
-            }
-            c[kCRcpW] = 1.0 / (double)fr.width; c[kCRcpH] = 1.0 / (double)fr.height;
-            c[kCScale] = fmax(fmax(fabs(fr.cam.eye[0]), fabs(fr.cam.eye[1])), fabs(fr.cam.eye[2])) + fabs(fr.cam.lens_z) + fabs(fr.cam.lens_w) + fabs(fr.cam.lens_h);
-            RRT_LDS uint32_t* cv = (RRT_LDS uint32_t*)(c + kCCover);
-            const uint64_t cp = (uint64_t)fr.cover;
-            cv[0] = (uint32_t)cp; cv[1] = (uint32_t)(cp >> 32);
-            cv[2] = fr.cover ? fr.n_cover : 0u; cv[3] = fr.cover_stride; cv[4] = fr.cover_bytes; cv[5] = 0u;
-        }
-        st.consts = c;
-    }
+    st.consts = stage_consts(sc, fr, smem + off);
     __syncthreads();
     return st;
 }
@@ -1673,33 +1701,53 @@ RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned 
 // about the same, go to different blocks), so the LDS staging is paid once per block.
 template <int CULL, bool GROUPS, bool SMALL, bool PL>
 __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
+    const uint32_t n_tiles = fr.npx_local >> 8;
+    // The slots this launch covers: with tile lists only the "heavy" ones (a primary ray through the tile can meet an
+    // entity; fr.order lists them first) -- the sky-only slots are k_sky's; without lists every slot.  The host sizes
+    // the grid for every slot; with lists the blocks beyond what the heavy chunks need leave at once.
+    const uint32_t n_work = fr.list_n ? fr.list_n[0] : n_tiles;
+    const uint32_t n_chunks = n_work * fr.ns;                                       // 256 paths per chunk
+    uint32_t grid = gridDim.x;
+    if (fr.list_n) {
+        uint32_t want = (n_chunks / fr.chunks_per_block + 2047u) / 2048u * 2048u;   // launch_primary's rule
+        if (want > n_chunks) want = n_chunks;
+        if (want > grid) want = grid;
+        if (want >= 8u) want -= want % 8u;
+        if (want == 0u) want = 1u;
+        if (blockIdx.x >= want) return;            // block-uniform, before any barrier
+        grid = want;
+    }
     extern __shared__ __align__(16) unsigned char smem[];
     const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, true);
-    const uint32_t n_chunks = (uint32_t)(((uint64_t)fr.ns * fr.npx_local) >> 8);   // 256 paths per chunk, exact
-    const uint32_t n_tiles = fr.npx_local >> 8;
 #if RRT_XCD_ORDER
-    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes the tiles
-    // t = x (mod 8), and its blocks walk them tile-major (all samples of a tile back to back, on
+    // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes the list entries
+    // k = x (mod 8), and its blocks walk them tile-major (all samples of a tile back to back, on
     // neighbouring blocks of the same XCD), so what one sample of a tile pulls in -- its leaves and
     // triangles, the sky texel lines behind it -- is in that L2 for the other samples.
-    const bool by_xcd = (gridDim.x & 7u) == 0u && n_tiles >= 8u;
+    const bool by_xcd = (grid & 7u) == 0u && n_work >= 8u;
     const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t limit = by_xcd ? ((n_tiles + 7u - xcd) >> 3) * fr.ns : n_chunks;
-    const uint32_t step = by_xcd ? gridDim.x >> 3 : gridDim.x;
+    const uint32_t limit = by_xcd ? ((n_work + 7u - xcd) >> 3) * fr.ns : n_chunks;
+    const uint32_t step = by_xcd ? grid >> 3 : grid;
     for (uint32_t m = by_xcd ? blockIdx.x >> 3 : blockIdx.x; m < limit; m += step) {
-        uint32_t chunk = m;
+        uint32_t kk, s_local;                      // list entry, sample (group) of this chunk
         if (by_xcd) {
-            const uint32_t k = m / fr.ns, s = m - k * fr.ns;
-            chunk = s * n_tiles + xcd + 8u * k;
+            const uint32_t k = m / fr.ns;
+            s_local = m - k * fr.ns;
+            kk = xcd + 8u * k;
+        } else {
+            s_local = m / n_work;
+            kk = m - s_local * n_work;
         }
 #else
-    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    for (uint32_t m = blockIdx.x; m < n_chunks; m += grid) {
+        uint32_t s_local = m / n_work;
+        const uint32_t kk = m - s_local * n_work;
 #endif
         // chunk = (sample, tile slot), or with sample packing (sample group and part of the tile, tile slot): see
         // path_of.  Wave-uniform, so the tile's position is scalar arithmetic.
+        const uint32_t slot = fr.order ? (uint32_t)fr.order[kk] : kk;
+        const uint32_t chunk = s_local * n_tiles + slot;
         const uint32_t path = chunk * 256u + threadIdx.x;
-        uint32_t s_local = chunk / n_tiles;
-        const uint32_t slot = chunk - s_local * n_tiles;
         uint32_t my_t = threadIdx.x;
         uint32_t tag_base = s_local * fr.npx_local + (slot << 8);
         if (fr.pack_log2) {
@@ -1709,39 +1757,17 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
             s_local = (s_local & ~sm) | (threadIdx.x & sm);
         }
         const uint32_t my_in = tile_swz(my_t);
-        const uint32_t tile = slot * fr.tile_world + fr.tile_rank;
-        const uint32_t ty = tile / fr.tiles_x;
-        uint32_t tx = tile - ty * fr.tiles_x;
-        if (fr.tile_skew) tx = (tx + fr.tile_skew * ty) % fr.tiles_x;      // wave-uniform: scalar arithmetic
+        uint32_t tx = 0, ty = 0;
+        const bool tile_ok = slot_pos(fr, slot, &tx, &ty);                 // wave-uniform: scalar arithmetic
         const uint32_t x = tx * RRT_TILE_W + (my_in & 31u), y = ty * RRT_TILE_H + (my_in >> 5);
-        const bool active = tile < fr.tiles_x * fr.tiles_y && x < fr.width && y < fr.height;
+        const bool active = tile_ok && x < fr.width && y < fr.height;
         const uint32_t sample = fr.s0 + s_local;
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         uint32_t cov = ~0u;
         // the tile's bin: a 64-bit scalar through the entity loop (parked in LDS and looked up per entity instead, to
         // spare the two SGPRs, it measured slower: cfg2 primary kernel 1.00 against 0.96 ms)
         uint64_t ebits = ~0ull;
-        if (CULL != 0 && fr.tile_bins && tile < fr.tiles_x * fr.tiles_y) ebits = fr.tile_bins[ty * fr.tiles_x + tx];   // scalar load
-        if (CULL == 1 && ebits == 0ull) {
-            // No entity can be met anywhere in this tile (four tiles of five on the UFO frame): every ray of the chunk
-            // ends in the sky.  Wave-uniform, so this is the whole iteration -- the same ray, the same texel, the same
-            // sample word as process_ray's miss arm, without the hit path's registers around it.
-            if (active) {
-                const RRT_GLOBAL uint8_t* tp;
-                if (!sky_texel_fast(fr, lds, x, y, sample, &tp)) {      // the texel is in doubt: the reference's chain
-                    primary_ray(fr, lds, x, y, sample, &o, &d);
-                    tp = sky_texel_ptr(sc, lds, d);
-                }
-                const uint32_t texel = (RRT_ABL & 1) ? 0u : ld_texel(tp);
-                if (sample == 0u) {
-                    const size_t pixel = (size_t)y * fr.width + x;
-                    if (d_ids) { d_ids[2 * pixel] = -1; d_ids[2 * pixel + 1] = -1; }
-                    if (d_t) d_t[pixel] = 0.0;
-                }
-                at_off<uint32_t>(wk.samp32, path * 4u) = kSampTexel | texel;
-            }
-            continue;
-        }
+        if (CULL != 0 && fr.tile_bins && tile_ok) ebits = fr.tile_bins[ty * fr.tiles_x + tx];   // scalar load
         if (active) {
             if (CULL != 0) cov = cover_bits(lds, x, y);       // requested before the ray is generated
             primary_ray(fr, lds, x, y, sample, &o, &d);
@@ -1749,6 +1775,177 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         process_ray<true, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample, tag_base,
                                             false, nullptr, nullptr, cov, ebits, chunk * 256u);
     }
+}
+
+// The sky-only slots of a batch (fr.order[list_n[0] .. list_n[1]): no entity can be met anywhere in the tile, four
+// tiles of five on the UFO frame): every primary ray ends in the sky, so a path is its ray's texel -- sky_texel_fast,
+// or the reference's own chain where that is in doubt -- and the 4-byte sample word.  A kernel of its own, because it
+// needs nothing of what the wavefront kernels carry (no descent arrays in LDS, no entity records, no hit path's
+// registers): a block stages 256 bytes of constants and runs at twice their occupancy, beside them on a second stream.
+// Same chunk geometry and path numbers as k_wave_primary.
+__global__ __launch_bounds__(256) void k_sky(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
+    __shared__ __align__(16) unsigned char cmem[kCDoubles * 8];
+    const uint32_t n_heavy = fr.list_n[0], n_sky = fr.list_n[1] - n_heavy;
+    const uint32_t n_chunks = n_sky * fr.ns;
+    if (blockIdx.x >= n_chunks) return;
+    StagedT<false> lds{nullptr, nullptr, nullptr, nullptr, nullptr};
+    lds.consts = stage_consts(sc, fr, cmem);
+    __syncthreads();
+    const uint32_t n_tiles = fr.npx_local >> 8;
+    // tile-major: neighbouring blocks take the samples of one tile, whose texels are neighbours in the cubemap
+    for (uint32_t m = blockIdx.x; m < n_chunks; m += gridDim.x) {
+        const uint32_t k = m / fr.ns;
+        uint32_t s_local = m - k * fr.ns;
+        const uint32_t slot = (uint32_t)fr.order[n_heavy + k];
+        const uint32_t path = (s_local * n_tiles + slot) * 256u + threadIdx.x;
+        uint32_t my_t = threadIdx.x;
+        if (fr.pack_log2) {
+            const uint32_t p = fr.pack_log2, sm = (1u << p) - 1u;
+            my_t = ((s_local & sm) << (8u - p)) | (threadIdx.x >> p);
+            s_local = (s_local & ~sm) | (threadIdx.x & sm);
+        }
+        const uint32_t my_in = tile_swz(my_t);
+        uint32_t tx = 0, ty = 0;
+        const bool tile_ok = slot_pos(fr, slot, &tx, &ty);
+        const uint32_t x = tx * RRT_TILE_W + (my_in & 31u), y = ty * RRT_TILE_H + (my_in >> 5);
+        if (!(tile_ok && x < fr.width && y < fr.height)) continue;
+        const uint32_t sample = fr.s0 + s_local;
+        const RRT_GLOBAL uint8_t* tp;
+        if (!sky_texel_fast(fr, lds, x, y, sample, &tp)) {      // the texel is in doubt: the reference's chain
+            V3 o, d;
+            primary_ray(fr, lds, x, y, sample, &o, &d);
+            tp = sky_texel_ptr(sc, lds, d);
+        }
+        const uint32_t texel = (RRT_ABL & 1) ? 0u : ld_texel(tp);
+        if (sample == 0u) {
+            const size_t pixel = (size_t)y * fr.width + x;
+            if (d_ids) { d_ids[2 * pixel] = -1; d_ids[2 * pixel + 1] = -1; }
+            if (d_t) d_t[pixel] = 0.0;
+        }
+        at_off<uint32_t>(wk.samp32, path * 4u) = kSampTexel | texel;
+    }
+}
+
+// Tile lists of a frame (DFrame::order / slot_tile / list_n), from the tile bins.  One block of 1024 threads: an
+// ordered (stable) compaction by class, so that every rank computes the same lists from the same bins.
+//   dealt = false: this rank's slots j (tile by the arithmetic map) in the order [heavy, sky-only, padding].
+//   dealt = true (rrt_settings::tile_deal): ALL tiles of the image in the order [a mesh can be met, only spheres can,
+//     sky only], each class in image order; position p of that sequence is slot p / world of rank p % world.  Every
+//     rank gets its share of each class (to within one tile) instead of whatever lies under its lattice of positions
+//     -- the ranks' frames then cost the same (the reference's own split, 12 contiguous pixel ranges, tracer.rs:117-158,
+//     is the opposite extreme).  The rank's slots are in class order already: order = 0, 1, 2, ...
+// all_heavy (cull mode 2 = verify): every valid slot counts as heavy, so that the wavefront kernels see every tile
+// and check the bins.
+RRT_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_tot, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    __syncthreads();                       // wave_tot may still be read from the previous call
+    if (lane == 63u) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (uint32_t w = 0; w < n_waves; ++w) {
+        const uint32_t t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+__global__ __launch_bounds__(1024) void k_lists(DFrame fr, uint64_t mesh_mask, uint32_t dealt, uint32_t all_heavy,
+                                                int32_t* slot_tile, int32_t* order, uint32_t* list_n) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t px_sum;
+    if (threadIdx.x == 0) px_sum = 0u;
+    const uint32_t n_img = fr.tiles_x * fr.tiles_y, W = fr.tile_world, r = fr.tile_rank;
+    const uint32_t n_items = dealt ? n_img : fr.n_slots;
+    const uint32_t per = (n_items + blockDim.x - 1u) / blockDim.x;
+    const uint32_t i0 = threadIdx.x * per, i1 = i0 + per < n_items ? i0 + per : n_items;
+    // class of item i: 0 = a mesh can be met, 1 = some entity can, 2 = sky only, 3 = padding slot (not dealt)
+    const auto cls_of = [&](uint32_t i, uint32_t* pos) -> uint32_t {
+        uint32_t p = i;
+        if (!dealt) {                        // slot i of this rank by the arithmetic map (slot_pos without a table)
+            const uint32_t tile = i * W + r;
+            if (tile >= n_img) return 3u;
+            const uint32_t ty = tile / fr.tiles_x;
+            uint32_t tx = tile - ty * fr.tiles_x;
+            if (fr.tile_skew) tx = (tx + fr.tile_skew * ty) % fr.tiles_x;
+            p = ty * fr.tiles_x + tx;
+        }
+        *pos = p;
+        const uint64_t b = fr.tile_bins[p];
+        if (all_heavy) return 0u;
+        return (b & mesh_mask) ? 0u : (b != 0ull ? 1u : 2u);
+    };
+    uint32_t cnt[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t i = i0; i < i1; ++i) { uint32_t p; ++cnt[cls_of(i, &p)]; }
+    uint32_t base[4], tot[4];
+    for (int c = 0; c < 4; ++c) base[c] = block_exclusive_scan(cnt[c], wave_tot, &tot[c]);
+    const uint32_t cbase[4] = {0u, tot[0], tot[0] + tot[1], tot[0] + tot[1] + tot[2]};
+    uint32_t my_px = 0u;
+    for (uint32_t i = i0; i < i1; ++i) {
+        uint32_t p = 0;
+        const uint32_t c = cls_of(i, &p);
+        const uint32_t pos = cbase[c] + base[c]++;
+        if (dealt) {
+            if (pos % W == r) {
+                const uint32_t slot = pos / W;
+                slot_tile[slot] = (int32_t)p;
+                order[slot] = (int32_t)slot;
+                const uint32_t ty = p / fr.tiles_x, tx = p - ty * fr.tiles_x;
+                const uint32_t w = fr.width - tx * RRT_TILE_W < RRT_TILE_W ? fr.width - tx * RRT_TILE_W : RRT_TILE_W;
+                const uint32_t h = fr.height - ty * RRT_TILE_H < RRT_TILE_H ? fr.height - ty * RRT_TILE_H : RRT_TILE_H;
+                my_px += w * h;
+            }
+        } else {
+            order[pos] = (int32_t)i;
+            if (c != 3u) {
+                const uint32_t ty = p / fr.tiles_x, tx = p - ty * fr.tiles_x;
+                const uint32_t w = fr.width - tx * RRT_TILE_W < RRT_TILE_W ? fr.width - tx * RRT_TILE_W : RRT_TILE_W;
+                const uint32_t h = fr.height - ty * RRT_TILE_H < RRT_TILE_H ? fr.height - ty * RRT_TILE_H : RRT_TILE_H;
+                my_px += w * h;
+            }
+        }
+    }
+    if (my_px) atomicAdd(&px_sum, my_px);
+    const auto share = [&](uint32_t n) { return n > r ? (n - r + W - 1u) / W : 0u; };    // positions p < n with p % W == r
+    if (dealt) {
+        // padding slots of this rank: the positions past the last tile
+        for (uint32_t slot = share(n_img) + threadIdx.x; slot < fr.n_slots; slot += blockDim.x) {
+            slot_tile[slot] = -1;
+            order[slot] = (int32_t)slot;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t heavy = tot[0] + tot[1];
+        list_n[0] = dealt ? share(heavy) : heavy;
+        list_n[1] = dealt ? share(n_img) : heavy + tot[2];
+        list_n[2] = px_sum;
+        list_n[3] = 0u;
+    }
+}
+
+// Dealt mode, root side: every rank's buffer is its slots' pixels followed by its slot -> tile table.
+__global__ __launch_bounds__(256) void k_assemble_dealt(const uint8_t* g, uint32_t w, uint32_t h, uint32_t world, uint32_t slots,
+                                                        uint32_t tiles_x, uint8_t* out) {
+    const uint32_t rs = blockIdx.x;                          // (rank, slot)
+    if (rs >= world * slots) return;
+    const uint32_t rank = rs / slots, slot = rs - rank * slots;
+    const size_t stride = (size_t)slots * (RRT_TILE_W * RRT_TILE_H * 3 + 4);
+    const uint8_t* base = g + (size_t)rank * stride;
+    const int32_t tile = ((const int32_t*)(base + (size_t)slots * RRT_TILE_W * RRT_TILE_H * 3))[slot];
+    if (tile < 0) return;
+    const uint32_t ty = (uint32_t)tile / tiles_x, tx = (uint32_t)tile - ty * tiles_x;
+    const uint32_t in = threadIdx.x, x = tx * RRT_TILE_W + (in & 31u), y = ty * RRT_TILE_H + (in >> 5);
+    if (x >= w || y >= h) return;
+    const uint8_t* src = base + ((size_t)slot * 256u + in) * 3;
+    uint8_t* dst = out + ((size_t)y * w + x) * 3;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
 }
 
 // A bounce level with at most this many rays runs in tail mode (see k_wave_bounce): fewer rays than the chip has
@@ -1763,8 +1960,10 @@ constexpr uint32_t kTailRays = 1u << 16;
 template <int CULL, bool GROUPS, bool SMALL, bool PL>
 __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const uint32_t n_live = wk.q_count[bounce], n_dead = wk.q_count[kMaxLevels + 1 + bounce], count = n_live + n_dead;
+    const unsigned long long qc = wk.q_count[bounce];
+    const uint32_t n_live = (uint32_t)qc, n_dead = (uint32_t)(qc >> 32), count = n_live + n_dead;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (bounce == 1u) atomicAdd(&wk.stats[3], (unsigned long long)n_dead);
         atomicAdd(&wk.stats[0], (unsigned long long)count);
         if (bounce < 4u) atomicAdd(&wk.stats[4 + bounce], (unsigned long long)count);
     }
@@ -2316,6 +2515,10 @@ inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) 
         return c == 0 ? name<0, false, false, false> : c == 1 ? name<1, false, false, false> : name<2, false, false, false>;         \
     }()
 
+uint32_t primary_chunks_per_block() {
+    static const uint32_t per_block = [] { const char* e = getenv("RRT_CHUNKS_PER_BLOCK"); const long v = e ? atol(e) : 0; return (uint32_t)(v > 0 ? v : 16); }();
+    return per_block;
+}
 void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
     // About sixteen 256-path chunks per persistent block, in a grid that is a multiple of 8 (the XCD-aware order) and of
     // at least 2048 blocks (a small launch still fills the chip).  Sweeps on the full cfg2 frame (130 k chunks), one
@@ -2324,7 +2527,7 @@ void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t
     // 36.1 Grays/s, 8: 35.4, 32: 35.3 (one frame at a time 8 is 2 % ahead).  Height field, 259 k chunks a launch: 16384
     // blocks 57.0 ms, 32768 56.5.
     const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
-    static const uint64_t per_block = [] { const char* e = getenv("RRT_CHUNKS_PER_BLOCK"); const long v = e ? atol(e) : 0; return (uint64_t)(v > 0 ? v : 16); }();
+    const uint64_t per_block = primary_chunks_per_block();
     uint64_t want = (chunks / per_block + 2047) / 2048 * 2048;      // in steps of 2048 blocks = two rounds of resident blocks
     if (want > chunks) want = chunks;
     if (want > trace_grid()) want = trace_grid();
@@ -2385,6 +2588,23 @@ void launch_bins(const DScene& sc, const DFrame& fr, void* stream) {
     const uint32_t n = fr.tiles_x * fr.tiles_y;
     hipLaunchKernelGGL(k_bins, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, sc, p, fr.cover, fr.cover ? fr.n_cover : 0u,
                        fr.cover_stride, fr.cover_bytes, const_cast<uint64_t*>(fr.tile_bins));
+}
+void launch_lists(const DFrame& fr, uint64_t mesh_mask, bool dealt, bool all_heavy, void* stream) {
+    hipLaunchKernelGGL(k_lists, dim3(1), dim3(1024), 0, (hipStream_t)stream, fr, mesh_mask, dealt ? 1u : 0u, all_heavy ? 1u : 0u,
+                       const_cast<int32_t*>(fr.slot_tile), const_cast<int32_t*>(fr.order), const_cast<uint32_t*>(fr.list_n));
+}
+void launch_sky(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
+    // sized for every slot being sky-only (the count is on the device): blocks beyond the work leave at once
+    const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
+    uint64_t want = (chunks + 7) / 8;
+    if (want > 16384) want = 16384;
+    if (want == 0) want = 1;
+    hipLaunchKernelGGL(k_sky, dim3((uint32_t)want), dim3(256), 0, (hipStream_t)stream, sc, wk, fr, d_ids, d_t);
+}
+void launch_assemble_dealt(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream) {
+    const uint32_t tiles_x = (w + RRT_TILE_W - 1) / RRT_TILE_W, tiles_y = (h + RRT_TILE_H - 1) / RRT_TILE_H;
+    const uint32_t slots = (tiles_x * tiles_y + world - 1) / world;
+    hipLaunchKernelGGL(k_assemble_dealt, dim3(world * slots), dim3(256), 0, (hipStream_t)stream, d_gathered, w, h, world, slots, tiles_x, d_rgb8);
 }
 void launch_assemble(const uint8_t* d_gathered, uint32_t w, uint32_t h, uint32_t world, uint8_t* d_rgb8, void* stream) {
     const uint32_t tiles_x = (w + RRT_TILE_W - 1) / RRT_TILE_W, tiles_y = (h + RRT_TILE_H - 1) / RRT_TILE_H;

@@ -31,8 +31,8 @@ def default_camera():
 
 
 def make_settings(width, height, spp=1, max_bounce=2, seed=0, prune_zero_mix=0,
-                  tile_rank=0, tile_world=1, batch_spp=0):
-    return B.Settings(width, height, spp, max_bounce, seed, prune_zero_mix, tile_rank, tile_world, batch_spp)
+                  tile_rank=0, tile_world=1, batch_spp=0, tile_deal=0):
+    return B.Settings(width, height, spp, max_bounce, seed, prune_zero_mix, tile_rank, tile_world, batch_spp, tile_deal)
 
 
 class loaders:
@@ -239,5 +239,12 @@ def tile_slots(width, height, world):
     return int(B.lib.rrt_tile_slots(width, height, world))
 
 
-def assemble_tiles(d_gathered, width, height, world, d_rgb8, stream=None):
-    B.check(B.lib.rrt_assemble_tiles(d_gathered, width, height, world, d_rgb8, stream))
+def tile_buffer_bytes(width, height, world, dealt=0):
+    return int(B.lib.rrt_tile_buffer_bytes(width, height, world, int(dealt)))
+
+
+def assemble_tiles(d_gathered, width, height, world, d_rgb8, stream=None, dealt=0):
+    if dealt:
+        B.check(B.lib.rrt_assemble_tiles_dealt(d_gathered, width, height, world, d_rgb8, stream))
+    else:
+        B.check(B.lib.rrt_assemble_tiles(d_gathered, width, height, world, d_rgb8, stream))
