@@ -32,7 +32,7 @@ Metric: Mrays/s, whole job.  A ray = one world-level closest-hit query (one
 reference semantics (prune_zero_mix = 0: the reflection ray is cast even when
 its mix is 0.0, as src/tracer.rs:195-201 does).
 
-Frames in flight: steps are enqueued round-robin on `--in-flight` streams (default 3; the scene keeps one set of work
+Frames in flight: steps are enqueued round-robin on `--in-flight` streams (default 4; the scene keeps one set of work
 buffers per stream), so the thin tail of one frame's launch chain (bounce levels, accumulate) runs under the next
 frame's primary kernel.  Every step is a complete frame; `value` is the throughput of K of them.  The figure with one
 frame at a time (the latency of a frame) is printed beside it (`one_frame_at_a_time`), and the per-kernel durations
@@ -96,7 +96,7 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel")
     ap.add_argument("--budget-gib", type=float, default=0.0, help="work-buffer budget in GiB (0 = library default)")
     ap.add_argument("--cull-mode", type=int, default=-1, help="rrt_set_cull_mode (0 off, 1 on, 2 verify; -1 = library default)")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("RRT_FRAMES_IN_FLIGHT", "3")),
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("RRT_FRAMES_IN_FLIGHT", "4")),
                     help="frames in flight (one stream and one set of work buffers each); 1 = one frame at a time")
     return ap.parse_args()
 
@@ -192,13 +192,15 @@ def flops_per_ray(per):
             + per["sphere_tests"] * F_SPHERE + F_SHADE)
 
 
-def io_bytes_per_ray(stats):
+def io_bytes_per_ray(stats, n_rays=None):
     """HBM I/O a primary ray cannot avoid: 3 B texel in + 4 B compact sample out when
     it ends in the sky; 56 B level record + 56 B queue entry + 4 B sample tag when the path continues, + 24 B
-    advance sample when the continuation ray is dead (mix 0.0)."""
+    advance sample when the continuation ray is dead (mix 0.0).  n_rays: the primary rays of the launch that is priced
+    (with tile lists the primary kernel holds the rays of the heavy tiles only; every continuing ray is among them)."""
     lv = stats["level_rays"]
-    cont = lv[1] / max(lv[0], 1)
-    dead = stats["zero_mix_paths"] / max(lv[0], 1)
+    n = max(n_rays if n_rays else lv[0], 1)
+    cont = lv[1] / n
+    dead = stats["zero_mix_paths"] / n
     return (1.0 - cont) * B_SKY + cont * B_CONT + dead * B_DEAD, cont, dead
 
 
@@ -291,7 +293,11 @@ def main():
     # RRT_BENCH_GATHER=native: the gather goes through librrt.so's own RCCL communicator (rrt_comm_*, the path of
     # a host without Python) instead of torch.distributed's; torch's group still carries the id and the barriers
     native = D.NativeComm(rank, world, dev) if world > 1 and os.environ.get("RRT_BENCH_GATHER", "torch") == "native" else None
-    pipe = D.TilePipeline(scene, w, h, world, dev, frame, native=native, depth=depth) if world > 1 else None
+    # N > 1: RRT_BENCH_DEAL=1 deals the tiles to the ranks by cost class (rrt_settings.tile_deal) instead of by position:
+    # measured on this frame it evens out the ranks (0.553-0.580 ms against 0.499-0.560) without making the slowest
+    # one faster, so the positional map stays the default
+    deal = 1 if os.environ.get("RRT_BENCH_DEAL", "0") != "0" else 0
+    pipe = D.TilePipeline(scene, w, h, world, dev, frame, native=native, depth=depth, dealt=bool(deal)) if world > 1 else None
     # no hipEvents between the launches of the timed frames (the sequential pass for the roofline turns them on; with
     # --in-flight 1 the timed pass is that sequential pass)
     scene.set_timing(2 if world == 1 and depth == 1 else 0)
@@ -304,7 +310,7 @@ def main():
     def measure(spp_total, in_flight):
         """-> (list of block seconds [max over ranks], stats of this rank's last frame)"""
         st = Hst.make_settings(w, h, spp=spp_total, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune,
-                               tile_rank=rank, tile_world=world, batch_spp=args.batch_spp)
+                               tile_rank=rank, tile_world=world, batch_spp=args.batch_spp, tile_deal=deal if world > 1 else 0)
 
         count = [0]
 
@@ -417,7 +423,7 @@ def main():
         # T(full) / 8 = load balance + fixed per-frame cost, everything but the gather itself.
         def frame_ms(tile_rank, tile_world, outs):
             st = Hst.make_settings(w, h, spp=STRONG_SPP, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune,
-                                   tile_rank=tile_rank, tile_world=tile_world)
+                                   tile_rank=tile_rank, tile_world=tile_world, tile_deal=deal if tile_world > 1 else 0)
             n = 12
             ts = []
             for rep in range(4):
@@ -433,9 +439,9 @@ def main():
         torch.cuda.synchronize()
         full_stats = scene.stats()
         full_rays = int(full_stats["rays_traced"])
-        locals_ = [D.alloc_tile_buffers(w, h, 8, dev)[0] for _ in range(depth)]
+        locals_ = [D.alloc_tile_buffers(w, h, 8, dev, dealt=bool(deal))[0] for _ in range(depth)]
         t_rank = [frame_ms(r, 8, locals_) for r in range(8)]
-        rank_share = {"tile_world": 8, "spp_total": STRONG_SPP, "frames_in_flight": depth, "t_full_ms": t_full, "t_rank_ms": t_rank,
+        rank_share = {"tile_world": 8, "tile_deal": deal, "spp_total": STRONG_SPP, "frames_in_flight": depth, "t_full_ms": t_full, "t_rank_ms": t_rank,
                       "rank_share_efficiency": (t_full / 8.0) / max(t_rank),
                       # the same frame as `value` above, re-timed here next to the rank frames (host clock, 12 frames)
                       "strong_frame_one_gpu": {"spp_total": STRONG_SPP, "ms_per_step": t_full, "rays_per_step": full_rays,
@@ -490,7 +496,7 @@ def main():
             line["rank_share_efficiency"] = rank_share["rank_share_efficiency"]
             line["rank_share"] = rank_share
         if world == 1:
-            line["config"]["kernel_ms"] = {"k_wave_primary": prim_ms, "k_wave_bounce": bnc_ms, "gpu": stats["gpu_ms"],
+            line["config"]["kernel_ms"] = {"k_wave_primary": prim_ms, "k_wave_bounce": bnc_ms, "k_sky": stats["sky_kernel_ms"], "gpu": stats["gpu_ms"],
                                            "k_wave_primary_launches": prim_n, "k_wave_bounce_launches": bnc_n}
         per = None
         if world == 1 and not args.no_cpu_baseline and args.config in ("cfg2", "cfg5"):
@@ -499,10 +505,19 @@ def main():
         if world == 1 and args.config in ("cfg2", "cfg5"):
             # Dominant kernel = k_wave_primary (one launch per wavefront batch); live hipEvent timing on the launch stream.
             launch_ms = prim_ms / max(prim_n, 1)
-            rays_per_launch = stats["primary_rays"] / max(prim_n, 1)
-            io_b, cont, dead = io_bytes_per_ray(stats)
+            # With tile lists the primary kernel traces the rays of the heavy tiles (a primary ray can meet an entity
+            # there); the sky-only tiles are k_sky's, which runs beside it on a second stream.
+            heavy_t, sky_t = stats["heavy_tiles"], stats["sky_tiles"]
+            heavy_frac = heavy_t / float(heavy_t + sky_t) if heavy_t + sky_t else 1.0
+            rays_per_launch = stats["primary_rays"] * heavy_frac / max(prim_n, 1)
+            sky_rays_per_launch = stats["primary_rays"] * (1.0 - heavy_frac) / max(prim_n, 1)
+            io_b, cont, dead = io_bytes_per_ray(stats, stats["primary_rays"] * heavy_frac)
             roof = {"kernel": "k_wave_primary", "avg_launch_ms": launch_ms, "launches_per_step": prim_n,
                     "rays_per_launch": rays_per_launch, "continuing_fraction": cont, "zero_mix_fraction": dead,
+                    "heavy_tiles": heavy_t, "sky_tiles": sky_t,
+                    "k_sky": {"ms_per_step": stats["sky_kernel_ms"], "rays_per_launch": sky_rays_per_launch,
+                              "what": "the primary rays of the sky-only tiles (no entity can be met in the tile): texel lookups, "
+                                      "on a second stream beside k_wave_primary; not part of `achieved`"},
                     "other_kernels": {"k_wave_bounce_ms_per_step": bnc_ms, "k_wave_bounce_launches": bnc_n,
                                       "k_wave_primary_ms_per_step": prim_ms, "gpu_ms_per_step": stats["gpu_ms"]}}
             traffic = attach_profiles(roof, args.config)
@@ -513,9 +528,15 @@ def main():
                 hbm = io_b * rays_per_launch / secs / 1e9
                 roof.update({"bound": "valu_f64", "unit": "TFLOP/s", "peak": PEAK_F64_TFLOPS, "traffic": traffic})
                 if per:
-                    fl = flops_per_ray(per)
+                    # `per` are means over ALL primary rays of the frame; a ray of a sky-only tile is priced by the same
+                    # formula at its two sphere tests, the mesh's root-box test and the shading constant: those rays are
+                    # k_sky's, so their flops come off the frame's total before it is put over the primary launch
+                    f_sky = 2 * F_SPHERE + 1 * F_BOX + F_SHADE
+                    n_all = rays_per_launch + sky_rays_per_launch
+                    fl = (flops_per_ray(per) * n_all - f_sky * sky_rays_per_launch) / max(rays_per_launch, 1.0)
                     ach = fl * rays_per_launch / secs / 1e12
-                    roof.update({"achieved": ach, "frac": ach / PEAK_F64_TFLOPS, "flops_per_ray": fl, "per_primary_ray": per,
+                    roof.update({"achieved": ach, "frac": ach / PEAK_F64_TFLOPS, "flops_per_ray": fl, "flops_per_ray_whole_frame": flops_per_ray(per),
+                                 "per_primary_ray": per,
                                  "formula": "N_tri*53 + N_box*30 + N_node*1 + N_sphere*25 + 120 (BASELINE.md section 3)",
                                  "note": "work delivered in the reference's flops (the cull skips most of the N_tri exact tests); "
                                          "no-FMA ceiling of this path = peak/2; issue-side figure in `executed`"})

@@ -103,7 +103,7 @@ struct TimedLaunch {
 
 struct WorkSet {
     hipStream_t stream = nullptr;
-    DevBuf w_q[2], w_rec, w_samp, w_samp32, w_accum, w_zero, w_bins, w_lists;   // w_zero: what a frame starts from zero, see zero_layout
+    DevBuf w_q[2], w_rec, w_samp, w_samp32, w_accum, w_zero, w_bins, w_lists, w_seg;   // w_zero: what a frame starts from zero, see zero_layout
     hipStream_t side = nullptr;                 // the sky kernel runs here, beside the wavefront kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t spp = 0;                           // of the last frame (rrt_get_stats: paths of a dealt frame = device count x spp)
@@ -638,6 +638,7 @@ uint64_t cover_stride(uint32_t width) { return ((uint64_t)(width + rrt::kCoverCe
 uint64_t cover_bytes(const rrt::DFrame& fr) { return (uint64_t)fr.n_cover * fr.cover_bytes; }
 // What every frame starts from zero sits in ONE block, so that it is one memset (each is a ~4 us kernel in the frame's
 // launch chain): the statistics, the queue counters (zeroed again in front of every further batch) and the coverage masks.
+constexpr uint64_t kSegBytes = 2ull * rrt::kMaxSegs * sizeof(rrt::uint2_);      // DWork::seg_n
 constexpr uint64_t kStatsBytes = 8 * 8, kQCountBytes = 2 * (rrt::kMaxLevels + 1) * 4, kListNBytes = 16;
 uint64_t zero_bytes(const rrt::DFrame& fr) { return 256 + cover_bytes(fr); }
 static_assert(kStatsBytes + kQCountBytes + kListNBytes <= 256, "statistics, queue counters and list counts share the block's first 256 bytes");
@@ -647,7 +648,7 @@ void zero_layout(unsigned char* base, FramePlan& pl, rrt::DWork* wk) {
     pl.fr.list_n = pl.want_lists ? (const uint32_t*)(base + kStatsBytes + kQCountBytes) : nullptr;
     pl.fr.cover = pl.fr.n_cover ? base + 256 : nullptr;
 }
-uint64_t bins_bytes(const rrt::DFrame& fr, bool want) { return want ? (uint64_t)fr.tiles_x * fr.tiles_y * 8 : 0; }
+uint64_t bins_bytes(const rrt::DFrame& fr, bool want) { return want ? (uint64_t)fr.tiles_x * fr.tiles_y * 9 : 0; }     // bins, then a cost byte per tile
 uint64_t lists_bytes(const rrt::DFrame& fr, bool want) { return want ? (uint64_t)fr.n_slots * 8 : 0; }     // order, then slot_tile
 void lists_layout(unsigned char* base, FramePlan& pl) {
     pl.fr.order = pl.want_lists ? (const int32_t*)base : nullptr;
@@ -663,6 +664,7 @@ int ensure_work(WorkSet* s, FramePlan& pl, rrt::DWork* wk) {
         HIP_TRY(s->w_lists.ensure(lists_bytes(pl.fr, true)));
     }
     pl.fr.tile_bins = pl.want_lists ? s->w_bins.as<uint64_t>() : nullptr;
+    pl.fr.tile_cost = pl.want_lists ? (const uint8_t*)(pl.fr.tile_bins + (size_t)pl.fr.tiles_x * pl.fr.tiles_y) : nullptr;
     lists_layout((unsigned char*)s->w_lists.p, pl);
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(s->w_q[i].ensure(P * rrt::kRecDoubles * 8));
@@ -672,6 +674,8 @@ int ensure_work(WorkSet* s, FramePlan& pl, rrt::DWork* wk) {
     HIP_TRY(s->w_samp.ensure(P * 3 * 8));
     HIP_TRY(s->w_samp32.ensure(P * 4));
     HIP_TRY(s->w_accum.ensure((size_t)pl.fr.npx_local * 3 * 8));
+    HIP_TRY(s->w_seg.ensure(kSegBytes));
+    wk->seg_n = s->w_seg.as<rrt::uint2_>();
 
     wk->rec = s->w_rec.as<double>();
     wk->samp = s->w_samp.as<double>();
@@ -688,7 +692,7 @@ uint64_t carve_bytes(const FramePlan& pl) {
     const uint64_t P = pl.cap;
     const uint64_t parts[] = {zero_bytes(pl.fr), P * rrt::kRecDoubles * 8, P * rrt::kRecDoubles * 8,
                               P * rrt::kRecDoubles * 8 * pl.levels, P * 3 * 8, P * 4, (uint64_t)pl.fr.npx_local * 3 * 8,
-                              bins_bytes(pl.fr, pl.want_lists), lists_bytes(pl.fr, pl.want_lists)};
+                              bins_bytes(pl.fr, pl.want_lists), lists_bytes(pl.fr, pl.want_lists), kSegBytes};
     uint64_t total = 0;
     for (uint64_t b : parts) total += (b + kCarveAlign - 1) / kCarveAlign * kCarveAlign;
     return total;
@@ -711,7 +715,9 @@ int carve_work(unsigned char* base, uint64_t bytes, FramePlan& pl, rrt::DWork* w
     wk->samp32 = (uint32_t*)take(P * 4);
     wk->accum = (double*)take((uint64_t)pl.fr.npx_local * 3 * 8);
     pl.fr.tile_bins = pl.want_lists ? (const uint64_t*)take(bins_bytes(pl.fr, true)) : nullptr;
+    pl.fr.tile_cost = pl.want_lists ? (const uint8_t*)(pl.fr.tile_bins + (size_t)pl.fr.tiles_x * pl.fr.tiles_y) : nullptr;
     lists_layout(take(lists_bytes(pl.fr, pl.want_lists)), pl);
+    wk->seg_n = (rrt::uint2_*)take(kSegBytes);
     wk->cap = P;
     return RRT_OK;
 }
@@ -771,12 +777,12 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         want_lists = want_bins || (st && st->tile_deal != 0 && st->tile_world > 1);
         if (want_lists && st && st->width && st->height) {
             const uint64_t n_img = (uint64_t)((st->width + 31) / 32) * ((st->height + 7) / 8);
-            mask_bytes += n_img * 8 + (n_img / (st->tile_world ? st->tile_world : 1) + 1) * 8 + 2 * kCarveAlign;
+            mask_bytes += n_img * 9 + (n_img / (st->tile_world ? st->tile_world : 1) + 1) * 8 + 2 * kCarveAlign;
         }
     };
     if (NOALLOC) count_masks();           // (an uncommitted scene is refused below)
     // the scratch block minus the two small headers; accum (24 B per pixel) is part of it
-    int rc = NOALLOC ? plan_frame(s, cam, st, &pl, rrt::kScratchBytes - 16 * kCarveAlign - mask_bytes, 3 * 8) : plan_frame(s, cam, st, &pl, s->work_budget);
+    int rc = NOALLOC ? plan_frame(s, cam, st, &pl, rrt::kScratchBytes - 16 * kCarveAlign - mask_bytes - kSegBytes, 3 * 8) : plan_frame(s, cam, st, &pl, s->work_budget);
     if (rc) {
         if (NOALLOC && rc == RRT_E_NOMEM)
             g_err = "rrt_render_device_noalloc: frame too large for the " + std::to_string(rrt::kScratchBytes >> 20) +
@@ -857,6 +863,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         fr.s0 = b * pl.batch_spp;
         fr.ns = std::min(pl.batch_spp, st->spp - fr.s0);
         fr.pack_log2 = sample_pack_log2(fr.ns);
+        fr.seg_grid = rrt::primary_grid(fr);
         if (b > 0) HIP_TRY(hipMemsetAsync(wk.q_count, 0, kQCountBytes, stream));
         TimedLaunch* tl = nullptr;
         if (pl.want_lists) {

@@ -222,9 +222,12 @@ constexpr int32_t kTopLink = -2;         // DNodeI::axis of a top-array entry th
 //   queue entry  {o.xyz, d.xyz, (u32 path, i32 medium)}   medium = sphere entity the ray travels inside, -1 = none
 //   level record {A.xyz = color*ambient + L*mixL, Pm.xyz = P*mixP, mixR}
 constexpr int kRecDoubles = 7;
+constexpr uint32_t kMaxSegs = 32768;     // queue segments = blocks of the primary kernel's grid at most
+struct uint2_ { uint32_t x, y; };        // (uint2 without the HIP headers: this file is also host C++)
 struct DWork {
     double* q[2];        // [P][7]          ray queues (read / written alternately by the bounce levels)
-    unsigned long long* q_count;   // [kMaxLevels + 1] queue entries per bounce level: low word = live rays (from the front), high word = dead rays (from the back)
+    unsigned long long* q_count;   // [kMaxLevels + 1] rays queued for each bounce level (one atomic per block): a level without rays leaves on one load
+    uint2_* seg_n;       // [2][kMaxSegs] per queue segment {live rays, dead rays} of the level about to be cast (parity = level & 1)
     double* rec;         // [levels][P][7]  shading records of the continuing casts
     double* samp;        // [P][3]          finished per-sample colour ...
     uint32_t* samp32;    // [P]             ... unless this says kSampTexel | sky texel (a primary ray that ended in the sky)
@@ -253,6 +256,7 @@ struct DFrame {
     // grid), bit e clear = no primary ray through that tile can be answered by entity e (a sphere whose projected
     // bounds miss the tile, a mesh whose coverage mask is clear over it).  Scenes of at most 64 entities.
     const uint64_t* tile_bins;
+    const uint8_t* tile_cost;    // beside the bins: a cost estimate per tile (0..127: cells of 4 pixels in which something can be met), k_bins
     // Tile lists of this frame (k_lists; present whenever tile_bins is).  `order`: the rank's tile slots in processing
     // order -- first the list_n[0] slots whose tile a primary ray can meet an entity in ("heavy": k_wave_primary), then,
     // up to list_n[1], the slots behind which there is only sky (k_sky); padding slots last.  `slot_tile` (dealt mode,
@@ -263,7 +267,7 @@ struct DFrame {
     const int32_t* order;
     const uint32_t* list_n;
     uint32_t chunks_per_block;   // 256-path chunks a persistent block of the primary kernel is sized for
-    uint32_t pad_;
+    uint32_t seg_grid;           // grid the batch's primary kernel is launched with (primary_grid): the queue segments follow from it
 };
 
 // Tile t (t % tile_world = owner, t / tile_world = slot) is the tile in row ty = t / tiles_x of the image, column
@@ -297,6 +301,7 @@ void launch_bins(const DScene& sc, const DFrame& fr, void* stream);
 // Fills fr.order / fr.list_n (and fr.slot_tile when `dealt`) from fr.tile_bins; mesh_mask = entity bits that are meshes.
 void launch_lists(const DFrame& fr, uint64_t mesh_mask, bool dealt, bool all_heavy, void* stream);
 uint32_t primary_chunks_per_block();
+uint32_t primary_grid(const DFrame& fr);
 // The sky-only slots of the batch (fr.order[list_n[0] .. list_n[1])): texel words into wk.samp32, AOVs of sample 0.
 void launch_sky(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream);
 // Dealt mode: [world][slots x 768 B pixels, slots x int32 tile table] -> row-major frame.

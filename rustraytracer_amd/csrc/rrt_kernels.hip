@@ -1209,12 +1209,34 @@ RRT_DEV void ld_rec(double* level_base, uint32_t idx, V3* A, V3* Pm, double* mix
     *Pm = mk(b.y, c.x, c.y);
 }
 
-// Wave-aggregated queue append: ONE atomic per wave for both ends of the queue.  A level's counter is 64 bits -- live
-// entries in the low word, dead entries in the high word (a batch holds fewer than 2^32 paths, so the low word never
-// carries).  Every wave of the chip adds to the same address, and such atomics are performed one after the other at
-// the memory side: with one atomic each for the live end, the dead end and a statistics counter the primary kernel of
-// the 1080p/64spp frame spent a third of its time (1.25 of 3.64 ms) queueing for them.
-RRT_DEV void queue_slots(unsigned long long* counter, bool live, bool dead, uint32_t* slot_live, uint32_t* slot_dead) {
+// Queue segments.  The ray queue of a level is cut into SEGMENTS, one per block of the primary kernel: the entries
+// [start, start + cap) that hold exactly the paths the block traces (its chunks x 256; the blocks' chunk counts follow
+// from the launch arithmetic, so the segments tile the queue without gaps: seg_layout / seg_range).  A block appends
+// the continuation rays of its paths to ITS segment -- live rays from the front, dead (mix 0.0) rays from the back,
+// through one 64-bit counter in LDS (low word live, high word dead; one wave-aggregated LDS atomic per wave) -- and
+// leaves the two counts in DWork::seg_n when it is done.  The bounce kernel of the next level takes the segments one
+// by one: the rays of segment s are cast by one block, whose continuation rays go to segment s of the other queue
+// (never more rays than came in, so they fit).  No global atomic is left on the path: the first version kept one
+// counter per level in device memory, and with every wave of the chip adding to the same address -- such atomics
+// are performed one after the other at the memory side -- the primary kernel of the 1080p/64spp frame spent a third
+// of its time (1.25 of 3.64 ms) queueing for them.
+struct SegOut {
+    RRT_LDS unsigned long long* cnt;   // the block's append counter
+    uint32_t start, cap;               // its region of the queue: one segment (the primary kernel) ...
+    // ... or (the bounce kernel) the concatenation of the block's n segments: cpre[i] = entries of the segments before
+    // i (cpre[n] = cap), starts[i] = first entry of segment i
+    const RRT_LDS uint32_t* cpre;
+    const RRT_LDS uint32_t* starts;
+    uint32_t n;
+};
+// entry of index j of the region
+RRT_DEV uint32_t seg_entry(const SegOut& seg, uint32_t j) {
+    if (seg.cpre == nullptr) return seg.start + j;
+    uint32_t i = 0u;
+    while (i + 1u < seg.n && j >= seg.cpre[i + 1u]) ++i;
+    return seg.starts[i] + (j - seg.cpre[i]);
+}
+RRT_DEV void queue_slots(RRT_LDS unsigned long long* counter, bool live, bool dead, uint32_t* slot_live, uint32_t* slot_dead) {
     const unsigned long long ml = __ballot(live), md = __ballot(dead);
     *slot_live = 0u; *slot_dead = 0u;
     if ((ml | md) == 0ull) return;
@@ -1222,10 +1244,67 @@ RRT_DEV void queue_slots(unsigned long long* counter, bool live, bool dead, uint
     const unsigned long long below = (1ull << lane) - 1ull;
     const int leader = __ffsll((long long)(ml | md)) - 1;
     unsigned long long base = 0ull;
-    if ((int)lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(ml) | ((unsigned long long)__popcll(md) << 32));
+    if ((int)lane == leader)
+        base = __hip_atomic_fetch_add(counter, (unsigned long long)__popcll(ml) | ((unsigned long long)__popcll(md) << 32), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_WORKGROUP);
     const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, leader, 64), bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader, 64);
     *slot_live = blo + (uint32_t)__popcll(ml & below);
     *slot_dead = bhi + (uint32_t)__popcll(md & below);
+}
+
+// How the primary kernel's launch cuts its chunks into blocks (and so the queues into segments).  host_grid = the grid
+// the primary kernel was launched with (DFrame::seg_grid); with tile lists only `grid` blocks of it have work.
+struct SegLayout {
+    uint32_t n_work;     // tile slots the launch covers (the heavy ones with lists, else all)
+    uint32_t n_chunks;   // n_work * ns
+    uint32_t grid;       // blocks with work = segments
+    bool by_xcd;
+};
+RRT_DEV SegLayout seg_layout(const DFrame& fr) {
+    SegLayout L;
+    L.n_work = fr.list_n ? fr.list_n[0] : fr.npx_local >> 8;
+    L.n_chunks = L.n_work * fr.ns;
+    L.grid = fr.seg_grid;
+    if (fr.list_n) {
+        uint32_t want = (L.n_chunks / fr.chunks_per_block + 2047u) / 2048u * 2048u;   // launch_primary's rule
+        if (want > L.n_chunks) want = L.n_chunks;
+        if (want > L.grid) want = L.grid;
+        if (want >= 8u) want -= want % 8u;
+        if (want == 0u) want = 1u;
+        L.grid = want;
+    }
+    L.by_xcd = RRT_XCD_ORDER && (L.grid & 7u) == 0u && L.n_work >= 8u;
+    return L;
+}
+// Block b of the layout: the chunk ordinals m = first, first + step, ... < limit of its list (XCD-aware order: the
+// list of XCD b & 7), and its queue segment [start, start + cap) in entries.
+struct SegRange {
+    uint32_t first, step, limit, xcd;
+    uint32_t start, cap;
+};
+RRT_DEV SegRange seg_range(const SegLayout& L, uint32_t ns, uint32_t b) {
+    SegRange R;
+    uint32_t xbase = 0u;
+    if (L.by_xcd) {
+        R.xcd = b & 7u;
+        R.first = b >> 3;
+        R.step = L.grid >> 3;
+        R.limit = ((L.n_work + 7u - R.xcd) >> 3) * ns;
+        // chunks of the XCDs before this one: sum over x' < xcd of ((n_work + 7 - x') >> 3) * ns
+        const uint32_t q8 = L.n_work >> 3, r8 = L.n_work & 7u;
+        xbase = (R.xcd * q8 + (R.xcd < r8 ? R.xcd : r8)) * ns;
+    } else {
+        R.xcd = 0u;
+        R.first = b;
+        R.step = L.grid;
+        R.limit = L.n_chunks;
+    }
+    const uint32_t q = R.limit / R.step, r = R.limit - q * R.step;      // blocks j < r of the list take q + 1 chunks
+    const uint32_t chunks = q + (R.first < r ? 1u : 0u);
+    const uint32_t before = R.first * q + (R.first < r ? R.first : r);
+    R.start = (xbase + before) * 256u;
+    R.cap = chunks * 256u;
+    return R;
 }
 
 // tracer.rs:84-110, 126-131 with the sub-pixel jitter extension.
@@ -1446,18 +1525,14 @@ RRT_DEV uint32_t cover_bits(LDS lds, uint32_t x, uint32_t y) {
 // 64-ray unit of the next level is then all live or all dead.  In one mixed queue the units were mixed too (waves of
 // UFO tiles and of sphere tiles append at the same time), and a unit costs what its dearest lane costs: measured
 // 10.7 k cycles for an all-dead unit against 43 k for one with live rays in it.
-RRT_DEV void enqueue_continuation(const DWork& wk, uint32_t bounce, bool cont, bool zero_mix, V3 ro, V3 rd, uint32_t path,
+RRT_DEV void enqueue_continuation(const DWork& wk, const SegOut& seg, uint32_t bounce, bool cont, bool zero_mix, V3 ro, V3 rd, uint32_t path,
                                   int32_t medium) {
-#if RRT_EXP_NOATOMIC       // timing experiment only (results are wrong): no queue counters at all, entry = path
-    const uint32_t slot_live = path, slot_dead = (uint32_t)wk.cap - 1u - path;
-#else
     uint32_t slot_live, slot_dead;
-    queue_slots(&wk.q_count[bounce + 1], cont && !zero_mix, cont && zero_mix, &slot_live, &slot_dead);
-#endif
+    queue_slots(seg.cnt, cont && !zero_mix, cont && zero_mix, &slot_live, &slot_dead);
     if (cont) {
         // queue entry {o.xyz, d.xyz, (path, medium)}
         double* q = wk.q[(bounce + 1) & 1];
-        const uint32_t slot = zero_mix ? (uint32_t)wk.cap - 1u - slot_dead : slot_live;
+        const uint32_t slot = seg_entry(seg, zero_mix ? seg.cap - 1u - slot_dead : slot_live);
         at_rec<f64x2>(q, slot, 0u) = f64x2{ro.x, ro.y};
         at_rec<f64x2>(q, slot, 16u) = f64x2{ro.z, rd.x};
         at_rec<f64x2>(q, slot, 32u) = f64x2{rd.y, rd.z};
@@ -1474,7 +1549,7 @@ struct NextRay {
 
 // `next` != nullptr (bounce kernel, tail mode): the continuation ray is handed back instead of being queued.
 template <bool PRIMARY, int CULL, bool GROUPS, bool PL, class LDS>
-RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFrame& fr, bool active,
+RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFrame& fr, const SegOut& seg, bool active,
                          uint32_t path, V3 o, V3 d, int32_t medium, uint32_t bounce, int32_t* d_ids, double* d_t,
                          uint32_t pixel, uint32_t sample, uint32_t tag_base, bool dead_sky = false,
                          unsigned long long* tacc = nullptr, NextRay* next = nullptr, uint32_t cov = ~0u, uint64_t ebits = ~0ull,
@@ -1588,7 +1663,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
         next->o = ro; next->d = rd; next->medium = medium; next->cont = cont; next->zero_mix = zero_mix;
         return;
     }
-    enqueue_continuation(wk, bounce, cont, zero_mix, ro, rd, path, medium);
+    enqueue_continuation(wk, seg, bounce, cont, zero_mix, ro, rd, path, medium);
 }
 
 // Bytes of LDS stage_scene fills (descent array, then entity records); the bounce kernel's unit
@@ -1705,44 +1780,29 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
     // The slots this launch covers: with tile lists only the "heavy" ones (a primary ray through the tile can meet an
     // entity; fr.order lists them first) -- the sky-only slots are k_sky's; without lists every slot.  The host sizes
     // the grid for every slot; with lists the blocks beyond what the heavy chunks need leave at once.
-    const uint32_t n_work = fr.list_n ? fr.list_n[0] : n_tiles;
-    const uint32_t n_chunks = n_work * fr.ns;                                       // 256 paths per chunk
-    uint32_t grid = gridDim.x;
-    if (fr.list_n) {
-        uint32_t want = (n_chunks / fr.chunks_per_block + 2047u) / 2048u * 2048u;   // launch_primary's rule
-        if (want > n_chunks) want = n_chunks;
-        if (want > grid) want = grid;
-        if (want >= 8u) want -= want % 8u;
-        if (want == 0u) want = 1u;
-        if (blockIdx.x >= want) return;            // block-uniform, before any barrier
-        grid = want;
-    }
+    const SegLayout L = seg_layout(fr);
+    if (blockIdx.x >= L.grid) return;              // block-uniform, before any barrier
+    const uint32_t n_work = L.n_work;
+    const SegRange R = seg_range(L, fr.ns, blockIdx.x);
     extern __shared__ __align__(16) unsigned char smem[];
-    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, true);
-#if RRT_XCD_ORDER
+    RRT_LDS unsigned long long* seg_cnt = (RRT_LDS unsigned long long*)(smem + lds_layout_bytes(sc));
+    if (threadIdx.x == 0) *seg_cnt = 0ull;
+    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, true);      // ends with the barrier that also publishes *seg_cnt
+    const SegOut seg{seg_cnt, R.start, R.cap, nullptr, nullptr, 1u};
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes the list entries
     // k = x (mod 8), and its blocks walk them tile-major (all samples of a tile back to back, on
     // neighbouring blocks of the same XCD), so what one sample of a tile pulls in -- its leaves and
     // triangles, the sky texel lines behind it -- is in that L2 for the other samples.
-    const bool by_xcd = (grid & 7u) == 0u && n_work >= 8u;
-    const uint32_t xcd = blockIdx.x & 7u;
-    const uint32_t limit = by_xcd ? ((n_work + 7u - xcd) >> 3) * fr.ns : n_chunks;
-    const uint32_t step = by_xcd ? grid >> 3 : grid;
-    for (uint32_t m = by_xcd ? blockIdx.x >> 3 : blockIdx.x; m < limit; m += step) {
+    for (uint32_t m = R.first; m < R.limit; m += R.step) {
         uint32_t kk, s_local;                      // list entry, sample (group) of this chunk
-        if (by_xcd) {
+        if (L.by_xcd) {
             const uint32_t k = m / fr.ns;
             s_local = m - k * fr.ns;
-            kk = xcd + 8u * k;
+            kk = R.xcd + 8u * k;
         } else {
             s_local = m / n_work;
             kk = m - s_local * n_work;
         }
-#else
-    for (uint32_t m = blockIdx.x; m < n_chunks; m += grid) {
-        uint32_t s_local = m / n_work;
-        const uint32_t kk = m - s_local * n_work;
-#endif
         // chunk = (sample, tile slot), or with sample packing (sample group and part of the tile, tile slot): see
         // path_of.  Wave-uniform, so the tile's position is scalar arithmetic.
         const uint32_t slot = fr.order ? (uint32_t)fr.order[kk] : kk;
@@ -1772,8 +1832,17 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
             if (CULL != 0) cov = cover_bits(lds, x, y);       // requested before the ray is generated
             primary_ray(fr, lds, x, y, sample, &o, &d);
         }
-        process_ray<true, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample, tag_base,
+        process_ray<true, CULL, GROUPS, PL>(sc, lds, wk, fr, seg, active, path, o, d, -1, 0u, d_ids, d_t, y * fr.width + x, sample, tag_base,
                                             false, nullptr, nullptr, cov, ebits, chunk * 256u);
+    }
+    // the segment's two counts, for the first bounce level
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long c = *seg_cnt;
+        wk.seg_n[(size_t)kMaxSegs + blockIdx.x] = uint2_{(uint32_t)c, (uint32_t)(c >> 32)};     // parity 1 = level 1
+        // the level's total, so that a launch of a level without rays leaves on one load (one atomic per BLOCK)
+        const unsigned long long n = (c & 0xffffffffull) + (c >> 32);
+        if (n) atomicAdd(&wk.q_count[1], n);
     }
 }
 
@@ -1836,85 +1905,115 @@ __global__ __launch_bounds__(256) void k_sky(DScene sc, DWork wk, DFrame fr, int
 //     is the opposite extreme).  The rank's slots are in class order already: order = 0, 1, 2, ...
 // all_heavy (cull mode 2 = verify): every valid slot counts as heavy, so that the wavefront kernels see every tile
 // and check the bins.
-RRT_DEV uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_tot, uint32_t* total) {
+RRT_DEV unsigned long long block_exclusive_scan(unsigned long long v, unsigned long long* wave_tot, unsigned long long* total) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    uint32_t incl = v;
+    unsigned long long incl = v;
 #pragma unroll
     for (uint32_t d = 1; d < 64u; d <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
-        if (lane >= d) incl += t;
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, d, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), d, 64);
+        if (lane >= d) incl += ((unsigned long long)hi << 32) | lo;
     }
     __syncthreads();                       // wave_tot may still be read from the previous call
     if (lane == 63u) wave_tot[wave] = incl;
     __syncthreads();
-    uint32_t base = 0, tot = 0;
+    unsigned long long base = 0, tot = 0;
     for (uint32_t w = 0; w < n_waves; ++w) {
-        const uint32_t t = wave_tot[w];
+        const unsigned long long t = wave_tot[w];
         if (w < wave) base += t;
         tot += t;
     }
     *total = tot;
     return base + incl - v;
 }
-__global__ __launch_bounds__(1024) void k_lists(DFrame fr, uint64_t mesh_mask, uint32_t dealt, uint32_t all_heavy,
+constexpr uint32_t kDealClasses = 16u;      // cost classes of the tiles in which an entity can be met (dealt mode)
+__global__ __launch_bounds__(1024) void k_lists(DFrame fr, uint64_t mesh_mask, uint32_t dealt, uint32_t all_heavy, uint32_t scatter,
                                                 int32_t* slot_tile, int32_t* order, uint32_t* list_n) {
-    __shared__ uint32_t wave_tot[16];
+    __shared__ unsigned long long wave_tot[16];
     __shared__ uint32_t px_sum;
     if (threadIdx.x == 0) px_sum = 0u;
     const uint32_t n_img = fr.tiles_x * fr.tiles_y, W = fr.tile_world, r = fr.tile_rank;
     const uint32_t n_items = dealt ? n_img : fr.n_slots;
     const uint32_t per = (n_items + blockDim.x - 1u) / blockDim.x;
     const uint32_t i0 = threadIdx.x * per, i1 = i0 + per < n_items ? i0 + per : n_items;
-    // class of item i: 0 = a mesh can be met, 1 = some entity can, 2 = sky only, 3 = padding slot (not dealt)
+    // Classes, dearest first.  dealt: the tiles of the image by the cost estimate of k_bins in kDealClasses steps, then
+    // (class kDealClasses) the tiles behind which there is only sky.  not dealt: this rank's slots -- 0 = an entity can
+    // be met, 1 = sky only, 2 = padding slot.
+    const uint32_t K = dealt ? kDealClasses + 1u : 3u, sky_class = dealt ? kDealClasses : 1u;
+    (void)mesh_mask;
     const auto cls_of = [&](uint32_t i, uint32_t* pos) -> uint32_t {
-        uint32_t p = i;
+        // dealt: item i is tile i * scatter mod n_img (scatter coprime to n_img, near 0.618 n_img): inside a class the
+        // tiles then follow each other in a scattered order instead of image order -- in image order the rows of a
+        // shape (the UFO is about 32 tiles wide) beat against the rounds of the deal, and the same ranks got the
+        // sparse edge tiles every time (measured: 6.8 % between the ranks' bounce rays, 2.4 % with the positional map)
+        uint32_t p = dealt ? (uint32_t)(((unsigned long long)i * scatter) % n_img) : i;
         if (!dealt) {                        // slot i of this rank by the arithmetic map (slot_pos without a table)
             const uint32_t tile = i * W + r;
-            if (tile >= n_img) return 3u;
+            if (tile >= n_img) return 2u;
             const uint32_t ty = tile / fr.tiles_x;
             uint32_t tx = tile - ty * fr.tiles_x;
             if (fr.tile_skew) tx = (tx + fr.tile_skew * ty) % fr.tiles_x;
             p = ty * fr.tiles_x + tx;
         }
         *pos = p;
-        const uint64_t b = fr.tile_bins[p];
-        if (all_heavy) return 0u;
-        return (b & mesh_mask) ? 0u : (b != 0ull ? 1u : 2u);
+        const bool heavy = all_heavy || fr.tile_bins[p] != 0ull;
+        if (!dealt) return heavy ? 0u : 1u;
+        if (!heavy) return sky_class;
+        const uint32_t cost = fr.tile_cost[p] & 127u;
+        return (kDealClasses - 1u) - cost * kDealClasses / 128u;
     };
-    uint32_t cnt[4] = {0u, 0u, 0u, 0u};
-    for (uint32_t i = i0; i < i1; ++i) { uint32_t p; ++cnt[cls_of(i, &p)]; }
-    uint32_t base[4], tot[4];
-    for (int c = 0; c < 4; ++c) base[c] = block_exclusive_scan(cnt[c], wave_tot, &tot[c]);
-    const uint32_t cbase[4] = {0u, tot[0], tot[0] + tot[1], tot[0] + tot[1] + tot[2]};
-    uint32_t my_px = 0u;
-    for (uint32_t i = i0; i < i1; ++i) {
-        uint32_t p = 0;
-        const uint32_t c = cls_of(i, &p);
-        const uint32_t pos = cbase[c] + base[c]++;
-        if (dealt) {
-            if (pos % W == r) {
-                const uint32_t slot = pos / W;
-                slot_tile[slot] = (int32_t)p;
-                order[slot] = (int32_t)slot;
-                const uint32_t ty = p / fr.tiles_x, tx = p - ty * fr.tiles_x;
-                const uint32_t w = fr.width - tx * RRT_TILE_W < RRT_TILE_W ? fr.width - tx * RRT_TILE_W : RRT_TILE_W;
-                const uint32_t h = fr.height - ty * RRT_TILE_H < RRT_TILE_H ? fr.height - ty * RRT_TILE_H : RRT_TILE_H;
-                my_px += w * h;
-            }
-        } else {
-            order[pos] = (int32_t)i;
-            if (c != 3u) {
-                const uint32_t ty = p / fr.tiles_x, tx = p - ty * fr.tiles_x;
-                const uint32_t w = fr.width - tx * RRT_TILE_W < RRT_TILE_W ? fr.width - tx * RRT_TILE_W : RRT_TILE_W;
-                const uint32_t h = fr.height - ty * RRT_TILE_H < RRT_TILE_H ? fr.height - ty * RRT_TILE_H : RRT_TILE_H;
-                my_px += w * h;
+    const auto tile_px = [&](uint32_t p) -> uint32_t {
+        const uint32_t ty = p / fr.tiles_x, tx = p - ty * fr.tiles_x;
+        const uint32_t w = fr.width - tx * RRT_TILE_W < RRT_TILE_W ? fr.width - tx * RRT_TILE_W : RRT_TILE_W;
+        const uint32_t h = fr.height - ty * RRT_TILE_H < RRT_TILE_H ? fr.height - ty * RRT_TILE_H : RRT_TILE_H;
+        return w * h;
+    };
+    // Stable compaction by class, two classes a scan (32-bit counts in one 64-bit word).  Dealt: position p of the
+    // sorted sequence belongs to round p / W, and the rounds are dealt to the ranks to and fro (round 0: ranks 0 .. W-1,
+    // round 1: W-1 .. 0, ...), so that every rank takes one tile of every W neighbours in cost and the dearer and the
+    // cheaper end of each round alternate: the ranks' sums differ by less than one tile's cost.  Slot = round.
+    uint32_t run_base = 0u, heavy_total = 0u, my_px = 0u;
+    for (uint32_t g0 = 0; g0 < K; g0 += 2u) {
+        unsigned long long cnt = 0ull;
+        for (uint32_t i = i0; i < i1; ++i) {
+            uint32_t p;
+            const uint32_t c = cls_of(i, &p);
+            if (c == g0) cnt += 1ull;
+            else if (c == g0 + 1u) cnt += 1ull << 32;
+        }
+        unsigned long long tot;
+        const unsigned long long base = block_exclusive_scan(cnt, wave_tot, &tot);
+        const uint32_t cb0 = run_base, cb1 = run_base + (uint32_t)tot;
+        uint32_t off0 = (uint32_t)base, off1 = (uint32_t)(base >> 32);
+        for (uint32_t i = i0; i < i1; ++i) {
+            uint32_t p = 0;
+            const uint32_t c = cls_of(i, &p);
+            if (c != g0 && c != g0 + 1u) continue;
+            const uint32_t pos = c == g0 ? cb0 + off0++ : cb1 + off1++;
+            if (dealt) {
+                const uint32_t round = pos / W, idx = pos - round * W;
+                if (((round & 1u) ? W - 1u - idx : idx) == r) {
+                    slot_tile[round] = (int32_t)p;
+                    order[round] = (int32_t)round;
+                    my_px += tile_px(p);
+                }
+            } else {
+                order[pos] = (int32_t)i;
+                if (c != 2u) my_px += tile_px(p);
             }
         }
+        run_base = cb1 + (uint32_t)(tot >> 32);
+        if (g0 < sky_class) heavy_total += (uint32_t)tot;
+        if (g0 + 1u < sky_class) heavy_total += (uint32_t)(tot >> 32);
     }
     if (my_px) atomicAdd(&px_sum, my_px);
-    const auto share = [&](uint32_t n) { return n > r ? (n - r + W - 1u) / W : 0u; };    // positions p < n with p % W == r
+    // positions p < n that are this rank's (rounds dealt to and fro)
+    const auto share = [&](uint32_t n) -> uint32_t {
+        const uint32_t full = n / W, rem = n - full * W;
+        const bool extra = rem != 0u && ((full & 1u) ? r >= W - rem : r < rem);
+        return full + (extra ? 1u : 0u);
+    };
     if (dealt) {
-        // padding slots of this rank: the positions past the last tile
+        // padding slots of this rank: the rounds it has no tile in
         for (uint32_t slot = share(n_img) + threadIdx.x; slot < fr.n_slots; slot += blockDim.x) {
             slot_tile[slot] = -1;
             order[slot] = (int32_t)slot;
@@ -1922,9 +2021,8 @@ __global__ __launch_bounds__(1024) void k_lists(DFrame fr, uint64_t mesh_mask, u
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t heavy = tot[0] + tot[1];
-        list_n[0] = dealt ? share(heavy) : heavy;
-        list_n[1] = dealt ? share(n_img) : heavy + tot[2];
+        list_n[0] = dealt ? share(heavy_total) : heavy_total;
+        list_n[1] = dealt ? share(n_img) : (n_img > r ? (n_img - r + W - 1u) / W : 0u);      // valid slots (not dealt: j * W + r < n_img)
         list_n[2] = px_sum;
         list_n[3] = 0u;
     }
@@ -1948,61 +2046,117 @@ __global__ __launch_bounds__(256) void k_assemble_dealt(const uint8_t* g, uint32
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
 }
 
-// A bounce level with at most this many rays runs in tail mode (see k_wave_bounce): fewer rays than the chip has
-// wave slots for (256 CUs x 16 waves x 64 lanes = 262 144), so re-queueing them level by level only adds launches.
-constexpr uint32_t kTailRays = 1u << 16;
+// A block of the bounce kernel whose segments hold at most this many rays (one unit a wave) runs in tail mode (see
+// k_wave_bounce): it carries every path on to its end, and the deeper levels find its segments empty.
+constexpr uint32_t kTailBlock = 256u;
+constexpr uint32_t kSegPerBlock = 16u;      // segments a block of the bounce kernel takes at most (kMaxSegs / the smallest bounce grid)
 
-// Bounce level `bounce`: the queue is cut into units of 64 rays; block b owns units b, b + grid, ...
-// and its four waves pull them from a counter in LDS.  Rays of a bounce level differ in cost by
+// Bounce level `bounce`.  The queue comes in segments (see SegOut): block b takes the segments b, b + grid, ... one
+// after the other; a segment is cut into units of 64 rays -- live units from its front, dead units from its back --
+// which the block's four waves pull from a counter in LDS.  Rays of a bounce level differ in cost by
 // more than an order of magnitude (a reflection that leaves the UFO at once vs. one that walks a
 // dozen leaves inside it); with one fixed 64-ray slice per wave and round, a block kept its LDS and
 // register slots until its slowest wave was done (measured: 2.4 of 4 waves/SIMD resident).
 template <int CULL, bool GROUPS, bool SMALL, bool PL>
 __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const unsigned long long qc = wk.q_count[bounce];
-    const uint32_t n_live = (uint32_t)qc, n_dead = (uint32_t)(qc >> 32), count = n_live + n_dead;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (bounce == 1u) atomicAdd(&wk.stats[3], (unsigned long long)n_dead);
-        atomicAdd(&wk.stats[0], (unsigned long long)count);
-        if (bounce < 4u) atomicAdd(&wk.stats[4 + bounce], (unsigned long long)count);
-    }
-    const uint32_t live_units = (n_live + 63u) >> 6, n_units = live_units + ((n_dead + 63u) >> 6);
-    if (blockIdx.x >= n_units) return;          // whole block idle (block-uniform): skip the staging too
-    const bool tail = count <= kTailRays;       // grid-uniform: every block reads the same two counters
-    const uint32_t my_units = (n_units - blockIdx.x + gridDim.x - 1u) / gridDim.x;
+    const SegLayout L = seg_layout(fr);
+    const uint32_t n_seg = L.grid;
+    const uint2_* seg_in = wk.seg_n + (size_t)(bounce & 1u) * kMaxSegs;
+    uint2_* seg_out = wk.seg_n + (size_t)((bounce + 1u) & 1u) * kMaxSegs;
+    // This block's segments sg_i = blockIdx.x + i * gridDim.x (at most kSegPerBlock of them: launch_bounce sizes the
+    // grid) are treated as ONE region, their concatenation in the order i = 0, 1, ...: the live rays of all of them
+    // form one sequence that is cut into units of 64 (then the dead rays likewise), whatever segment a ray sits in,
+    // and the continuation rays go to the front (live) and the back (dead) of the concatenation of the same segments
+    // in the other queue -- never more rays than came in, so they fit.  Per-segment units (the first version) left the
+    // deeper levels with a handful of rays per unit (the 222 k second-level rays of the 64-spp frame in 8192 segments:
+    // 27 a unit), and a barrier per segment left three waves idle at the end of every segment.
     RRT_LDS uint32_t* next_unit = (RRT_LDS uint32_t*)(smem + lds_layout_bytes(sc));
-    if (threadIdx.x == 0) *next_unit = 0u;
-    // a block with a single 64-ray unit (the thin last levels) descends from global memory rather than copy the array
-    // (a tail-mode unit casts its rays level after level: worth the copy as well)
-    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, my_units > 1u || tail);   // ends with the barrier that also publishes *next_unit
-    const uint64_t P = wk.cap;
+    RRT_LDS unsigned long long* s_cnt = (RRT_LDS unsigned long long*)(next_unit + 2);   // the block's append counter (low: live, high: dead)
+    RRT_LDS uint32_t* s_live = next_unit + 4;                      // [kSegPerBlock] live rays of segment i
+    RRT_LDS uint32_t* s_dead = s_live + kSegPerBlock;              // [kSegPerBlock] dead rays
+    RRT_LDS uint32_t* s_lpre = s_dead + kSegPerBlock;              // [kSegPerBlock + 1] live rays of the segments before i
+    RRT_LDS uint32_t* s_dpre = s_lpre + kSegPerBlock + 1;          // [kSegPerBlock + 1] dead rays ...
+    RRT_LDS uint32_t* s_cpre = s_dpre + kSegPerBlock + 1;          // [kSegPerBlock + 1] entries (capacity) ...
+    RRT_LDS uint32_t* s_start = s_cpre + kSegPerBlock + 1;         // [kSegPerBlock] first entry of segment i
+    RRT_LDS uint32_t* s_cap = s_start + kSegPerBlock;              // [kSegPerBlock]
+    const uint32_t my_nseg = blockIdx.x < n_seg ? (n_seg - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
+    if (wk.q_count[bounce] == 0ull) return;        // a level without rays (grid-uniform): nothing is read, nothing written
+    if (threadIdx.x < kSegPerBlock) {
+        uint2_ c{0u, 0u};
+        if (threadIdx.x < my_nseg) c = seg_in[blockIdx.x + threadIdx.x * gridDim.x];
+        s_live[threadIdx.x] = c.x;
+        s_dead[threadIdx.x] = c.y;
+    }
+    __syncthreads();
+    uint32_t mine = 0u, mine_dead = 0u;
+    for (uint32_t i = 0; i < my_nseg; ++i) { mine += s_live[i] + s_dead[i]; mine_dead += s_dead[i]; }
+    if (mine == 0u) {       // block-uniform: no rays here; the next level is told so, and the staging is skipped
+        if (threadIdx.x < my_nseg) seg_out[blockIdx.x + threadIdx.x * gridDim.x] = uint2_{0u, 0u};
+        return;
+    }
+    if (threadIdx.x < kSegPerBlock) {
+        uint32_t st = 0u, cp = 0u;
+        if (threadIdx.x < my_nseg) {
+            const SegRange R = seg_range(L, fr.ns, blockIdx.x + threadIdx.x * gridDim.x);
+            st = R.start; cp = R.cap;
+        }
+        s_start[threadIdx.x] = st;
+        s_cap[threadIdx.x] = cp;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (bounce == 1u) atomicAdd(&wk.stats[3], (unsigned long long)mine_dead);     // primary hits whose continuation ray is dead
+        atomicAdd(&wk.stats[0], (unsigned long long)mine);
+        if (bounce < 4u) atomicAdd(&wk.stats[4 + bounce], (unsigned long long)mine);
+        uint32_t al = 0u, ad = 0u, ac = 0u;
+        for (uint32_t i = 0; i < kSegPerBlock; ++i) {
+            s_lpre[i] = al; s_dpre[i] = ad; s_cpre[i] = ac;
+            al += s_live[i]; ad += s_dead[i]; ac += s_cap[i];
+        }
+        s_lpre[kSegPerBlock] = al; s_dpre[kSegPerBlock] = ad; s_cpre[kSegPerBlock] = ac;
+        *next_unit = 0u;
+        *s_cnt = 0ull;
+    }
+    const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, true);      // ends with the barrier that also publishes the above
+    const uint32_t n_live = s_lpre[kSegPerBlock], n_dead = s_dpre[kSegPerBlock];
+    const uint32_t live_units = (n_live + 63u) >> 6, my_units = live_units + ((n_dead + 63u) >> 6);
+    // a block with at most one unit a wave carries its paths to their ends (tail mode, below)
+    const bool tail = n_live + n_dead <= kTailBlock;
+    const SegOut seg{s_cnt, 0u, s_cpre[kSegPerBlock], s_cpre, s_start, my_nseg};
     double* q = wk.q[bounce & 1];
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long tk0 = TSTAMP();
     unsigned long long acc_q = 0, acc_p = 0, acc_n = 0, acc_dp = 0, acc_dn = 0, acc_lc = 0;
     (void)tk0; (void)acc_q; (void)acc_p; (void)acc_n; (void)acc_dp; (void)acc_dn; (void)acc_lc;
-    for (;;) {
+    {
+      for (;;) {
         const unsigned long long t0 = TSTAMP();
         (void)t0;
         uint32_t u = 0u;
         if (lane == 0u) u = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
         if (u >= my_units) break;               // wave-uniform; the counter only grows, so every wave gets here
-        // unit -> queue entries: live units count up from entry 0, dead units down from entry P - 1
-        const uint32_t unit = u * gridDim.x + blockIdx.x;
-        const bool live_unit = unit < live_units;
-        const uint32_t kk = (live_unit ? unit : unit - live_units) * 64u, k = kk + lane;
-        const bool active = k < (live_unit ? n_live : n_dead);
-        // entry ub + li: ub wave-uniform (P is a multiple of 256, so a dead unit's 64 entries are one aligned group too)
-        const uint32_t ub = live_unit ? kk : (uint32_t)P - 64u - kk, li = live_unit ? lane : 63u - lane;
+        // unit -> rays: live units count up through the live runs of the segments (each at its segment's front), dead
+        // units through the dead runs (each at its segment's back, downwards)
+        const bool live_unit = u < live_units;
+        const uint32_t g = (live_unit ? u : u - live_units) * 64u + lane;
+        const bool active = g < (live_unit ? n_live : n_dead);
+        uint32_t entry = 0u;
+        if (active) {
+            const RRT_LDS uint32_t* pre = live_unit ? s_lpre : s_dpre;
+            uint32_t i = 0u;
+            while (i + 1u < my_nseg && g >= pre[i + 1u]) ++i;
+            const uint32_t off = g - pre[i];
+            entry = live_unit ? s_start[i] + off : s_start[i] + s_cap[i] - 1u - off;
+        }
         V3 o = mk(0., 0., 0.), d = mk(0., 0., 1.);
         uint32_t path = 0;
         bool dead_sky = false;
         int32_t medium = -1;
         if (active) {
-            const f64x2 a = at_rec<f64x2>(q, ub, li, 0u), b = at_rec<f64x2>(q, ub, li, 16u), c = at_rec<f64x2>(q, ub, li, 32u);
-            const uint2 pm = at_rec<uint2>(q, ub, li, 48u);
+            const f64x2 a = at_rec<f64x2>(q, entry, 0u), b = at_rec<f64x2>(q, entry, 16u), c = at_rec<f64x2>(q, entry, 32u);
+            const uint2 pm = at_rec<uint2>(q, entry, 48u);
             o = mk(a.x, a.y, b.x);
             d = mk(b.y, c.x, c.y);
             path = pm.x & ~kDeadSky;
@@ -2024,7 +2178,7 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
             bool act = active;
             for (uint32_t b = bounce;;) {
                 NextRay nx;
-                process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, act, path, o, d, medium, b, nullptr, nullptr, 0u, 0u, 0u, dead_sky, &tch, &nx);
+                process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, seg, act, path, o, d, medium, b, nullptr, nullptr, 0u, 0u, 0u, dead_sky, &tch, &nx);
                 act = act && nx.cont;
                 const unsigned long long going = __ballot(act);
                 if (going == 0ull) break;
@@ -2037,12 +2191,28 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
                 o = nx.o; d = nx.d; medium = nx.medium; dead_sky = nx.zero_mix;
             }
         } else {
-            process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, 0u, dead_sky, &tch);
+            process_ray<false, CULL, GROUPS, PL>(sc, lds, wk, fr, seg, active, path, o, d, medium, bounce, nullptr, nullptr, 0u, 0u, 0u, dead_sky, &tch);
         }
         const unsigned long long t2 = TSTAMP();
         if (__ballot(active && !dead_sky) != 0ull) acc_lc += tch;
         acc_q += t1 - t0; acc_p += t2 - t1; acc_n += 1;
         if (__ballot(active && !dead_sky) == 0ull) { acc_dp += t2 - t1; acc_dn += 1; }
+      }
+    }
+    // The region is done when all four waves are.  Its continuation rays fill the concatenation from the front (live)
+    // and from the back (dead): what that leaves in segment i -- a run at its front, a run at its back -- are its two
+    // counts for the next level.
+    __syncthreads();
+    if (threadIdx.x < my_nseg) {
+        const unsigned long long c = *s_cnt;
+        const uint32_t tl = (uint32_t)c, td = (uint32_t)(c >> 32), total = s_cpre[kSegPerBlock];
+        const uint32_t c0 = s_cpre[threadIdx.x], c1 = c0 + s_cap[threadIdx.x];
+        const uint32_t live_i = tl > c0 ? (tl < c1 ? tl - c0 : c1 - c0) : 0u;
+        const uint32_t d0 = total - td;                                    // dead entries: [d0, total) of the concatenation
+        const uint32_t lo = d0 > c0 ? d0 : c0;
+        const uint32_t dead_i = c1 > lo ? c1 - lo : 0u;
+        seg_out[blockIdx.x + threadIdx.x * gridDim.x] = uint2_{live_i, dead_i};
+        if (threadIdx.x == 0 && tl + td != 0u) atomicAdd(&wk.q_count[bounce + 1u], (unsigned long long)tl + td);
     }
     if (bounce == 1u) { TADD(0, acc_q); TADD(1, acc_p); TADD(2, acc_n); TADD(3, TSTAMP() - tk0); TADD(4, 1); TADD(5, acc_dp); TADD(6, acc_dn); TADD(7, acc_lc); }
 }
@@ -2297,7 +2467,7 @@ struct BinParams {
     uint32_t width, height, tiles_x, tiles_y;
 };
 __global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint8_t* cover, uint32_t n_cover, uint32_t stride,
-                                              uint32_t bytes, uint64_t* bins) {
+                                              uint32_t bytes, uint64_t* bins, uint8_t* cost_out) {
     const uint32_t tile = blockIdx.x * 256u + threadIdx.x;
     if (tile >= p.tiles_x * p.tiles_y) return;
     const uint32_t ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
@@ -2305,10 +2475,15 @@ __global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint
     const double y0 = (double)(ty * RRT_TILE_H), y1 = fmin(y0 + (double)RRT_TILE_H, (double)p.height);
     const double sx = p.lens_z / p.lens_w * (double)p.width, sy = p.lens_z / p.lens_h * (double)p.height;
     uint64_t bits = ~0ull;
+    // an estimate of what the tile's primary rays will cost (the dealt tile map sorts by it): cells of 4 pixels of the
+    // tile that a mesh's coverage mask keeps, + cells inside the bounding rectangle of a sphere's image; 64 for an
+    // entity nothing is known about
+    uint32_t cost = 0u;
     for (int32_t e = 0; e < sc.n_ents && e < 64; ++e) {
         const DEntity ent = sc.ents[e];
         const int32_t kind = ent.kind & ~kEntityMember;
         bool may = true;
+        uint32_t ecost = kind == 2 ? 0u : 64u;
         if (kind == 0) {
             const DSphere S = sc.spheres[ent.index];
             const double cx = S.c[0] - p.eye[0], cy = S.c[1] - p.eye[1], cz = S.c[2] - p.eye[2];
@@ -2323,6 +2498,10 @@ __global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint
                 const double pylo = vlo * sy + 0.5 * (double)p.height - 1.0, pyhi = vhi * sy + 0.5 * (double)p.height + 1.0;
                 // written so that a NaN anywhere keeps the bit
                 if (pxhi < x0 || pxlo >= x1 || pyhi < y0 || pylo >= y1) may = false;
+                else if (pxhi >= pxlo && pyhi >= pylo) {
+                    const double ox = fmin(pxhi, x1) - fmax(pxlo, x0), oy = fmin(pyhi, y1) - fmax(pylo, y0);
+                    ecost = (uint32_t)fmin(64.0, fmax(1.0, ceil(ox / (double)kCoverCell) * ceil(oy)));
+                }
             }
         } else if (kind == 3) {
             // a bare Triangle: k_cover's projection (see there) with the triangle's own constants -- S its longer edge,
@@ -2354,12 +2533,18 @@ __global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint
                 // a tile row = 32 pixels = 8 cells = one aligned 8-byte word of the mask
                 const uint8_t* m = cover + (size_t)(cs - 1) * bytes;
                 uint64_t any = *(const uint64_t*)(m + bytes - 8u);
-                for (uint32_t y = ty * RRT_TILE_H; y < (ty + 1u) * RRT_TILE_H && y < p.height; ++y)
-                    any |= *(const uint64_t*)(m + (size_t)y * stride + 8u * tx);
+                uint32_t cells = any ? 64u : 0u;
+                for (uint32_t y = ty * RRT_TILE_H; y < (ty + 1u) * RRT_TILE_H && y < p.height; ++y) {
+                    const uint64_t wd = *(const uint64_t*)(m + (size_t)y * stride + 8u * tx);
+                    any |= wd;
+                    cells += (uint32_t)__popcll(wd & 0x0101010101010101ull);     // a set cell is a byte of value 1
+                }
                 may = any != 0ull;
+                ecost = cells < 64u ? cells : 64u;
             }
         }
         if (!may) bits &= ~(1ull << e);
+        else cost += ecost;
     }
     // a Scene<T> answers only through a member (scene.rs:50-52 = the kd walk over its members): no member that can be
     // met, no group.  (Members of any group count: with several groups that only keeps a bit too many.)
@@ -2372,6 +2557,7 @@ __global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint
     if ((bits & members) == 0ull && sc.n_ents <= 64) bits &= ~groups;
     if (sc.n_ents < 64) bits &= (1ull << sc.n_ents) - 1ull;      // no entity, no bit: 0 = "only sky behind this tile"
     bins[tile] = bits;
+    if (cost_out) cost_out[tile] = (uint8_t)(cost < 127u ? cost : 127u);
 }
 
 // [world][slots][8][32][3] -> row-major [H][W][3]
@@ -2479,7 +2665,7 @@ inline uint32_t trace_grid() {
     static const uint32_t g = [] {
         const char* e = getenv("RRT_TRACE_GRID");
         const long v = e ? atol(e) : 0;
-        return (uint32_t)(v > 0 && v <= 65535 ? v : 256 * 128);   // the cap; launch_primary sizes the grid by the chunk count
+        return (uint32_t)(v > 0 && v <= (long)kMaxSegs ? v : (long)kMaxSegs);   // the cap; launch_primary sizes the grid by the chunk count
     }();
     return g;
 }
@@ -2491,7 +2677,8 @@ inline uint32_t bounce_grid() {
     }();
     return g;
 }
-inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) + 16; }   // + the bounce kernel's unit counter
+// + the primary kernel's append counter / the bounce kernel's unit counter, append counter and segment tables
+inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) + 16 + (7 * kSegPerBlock + 3) * 4 + 4; }
 
 }  // namespace
 
@@ -2526,19 +2713,26 @@ void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t
     // most chunks are cheap and the per-block LDS staging weighs more: three frames in flight, 16 chunks a block give
     // 36.1 Grays/s, 8: 35.4, 32: 35.3 (one frame at a time 8 is 2 % ahead).  Height field, 259 k chunks a launch: 16384
     // blocks 57.0 ms, 32768 56.5.
+    auto k = RRT_PICK(k_wave_primary);
+    hipLaunchKernelGGL(k, dim3(fr.seg_grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, d_ids, d_t);      // fr.seg_grid = primary_grid(fr)
+}
+// The primary kernel's grid for a batch (every slot counted; with tile lists the kernel itself uses fewer blocks, see
+// seg_layout).  Also the number of queue segments the bounce kernels may meet: DFrame::seg_grid.
+uint32_t primary_grid(const DFrame& fr) {
     const uint64_t chunks = ((uint64_t)fr.ns * fr.npx_local) / 256;
     const uint64_t per_block = primary_chunks_per_block();
     uint64_t want = (chunks / per_block + 2047) / 2048 * 2048;      // in steps of 2048 blocks = two rounds of resident blocks
     if (want > chunks) want = chunks;
     if (want > trace_grid()) want = trace_grid();
     if (want >= 8) want -= want % 8;
-    const uint32_t grid = (uint32_t)(want ? want : 1);
-    auto k = RRT_PICK(k_wave_primary);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, d_ids, d_t);
+    return (uint32_t)(want ? want : 1);
 }
 void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream) {
     auto k = RRT_PICK(k_wave_bounce);
-    hipLaunchKernelGGL(k, dim3(bounce_grid()), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
+    uint32_t grid = bounce_grid();
+    const uint32_t need = (fr.seg_grid + kSegPerBlock - 1u) / kSegPerBlock;      // a block takes at most kSegPerBlock segments
+    if (grid < need) grid = (need + 7u) / 8u * 8u;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
 }
 void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream,
                        uint32_t tile0, uint32_t n_tiles) {
@@ -2587,10 +2781,18 @@ void launch_bins(const DScene& sc, const DFrame& fr, void* stream) {
     p.width = fr.width; p.height = fr.height; p.tiles_x = fr.tiles_x; p.tiles_y = fr.tiles_y;
     const uint32_t n = fr.tiles_x * fr.tiles_y;
     hipLaunchKernelGGL(k_bins, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, sc, p, fr.cover, fr.cover ? fr.n_cover : 0u,
-                       fr.cover_stride, fr.cover_bytes, const_cast<uint64_t*>(fr.tile_bins));
+                       fr.cover_stride, fr.cover_bytes, const_cast<uint64_t*>(fr.tile_bins), const_cast<uint8_t*>(fr.tile_cost));
 }
 void launch_lists(const DFrame& fr, uint64_t mesh_mask, bool dealt, bool all_heavy, void* stream) {
-    hipLaunchKernelGGL(k_lists, dim3(1), dim3(1024), 0, (hipStream_t)stream, fr, mesh_mask, dealt ? 1u : 0u, all_heavy ? 1u : 0u,
+    uint32_t scatter = 1u;
+    if (dealt) {
+        const uint32_t n = fr.tiles_x * fr.tiles_y;
+        const auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
+        scatter = (uint32_t)(0.6180339887498949 * (double)n) | 1u;
+        while (n > 1u && gcd(scatter % n, n) != 1u) scatter += 2u;
+        if (n <= 1u) scatter = 1u;
+    }
+    hipLaunchKernelGGL(k_lists, dim3(1), dim3(1024), 0, (hipStream_t)stream, fr, mesh_mask, dealt ? 1u : 0u, all_heavy ? 1u : 0u, scatter,
                        const_cast<int32_t*>(fr.slot_tile), const_cast<int32_t*>(fr.order), const_cast<uint32_t*>(fr.list_n));
 }
 void launch_sky(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {

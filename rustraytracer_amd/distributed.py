@@ -14,9 +14,14 @@ import torch.distributed as dist
 from . import tiles
 
 
-def alloc_tile_buffers(width, height, world, device):
+def alloc_tile_buffers(width, height, world, device, dealt=False):
+    """A rank's compact tile buffer and the gathered one.  dealt (rrt_settings.tile_deal): flat bytes -- the slots'
+    pixels followed by the rank's int32 slot -> tile table (tiles.dealt_buffer_bytes)."""
     slots = tiles.tile_slots(width, height, world)
-    local = torch.zeros((slots, tiles.TILE_H, tiles.TILE_W, 3), dtype=torch.uint8, device=device)
+    if dealt and world > 1:
+        local = torch.zeros((tiles.dealt_buffer_bytes(width, height, world),), dtype=torch.uint8, device=device)
+    else:
+        local = torch.zeros((slots, tiles.TILE_H, tiles.TILE_W, 3), dtype=torch.uint8, device=device)
     gathered = torch.zeros((world,) + tuple(local.shape), dtype=torch.uint8, device=device)
     return local, gathered
 
@@ -50,8 +55,9 @@ class NativeComm:
         B.check(B.lib.rrt_set_device(device.index if device.index is not None else 0))
         B.check(B.lib.rrt_comm_init(rank, world, raw, C.byref(self.h)))
 
-    def gather(self, local, gathered, width, height, root=-1, stream=None):
-        self._B.check(self._B.lib.rrt_gather_tiles(self.h, local.data_ptr(), gathered.data_ptr(), width, height, root, stream))
+    def gather(self, local, gathered, width, height, root=-1, stream=None, dealt=False):
+        fn = self._B.lib.rrt_gather_tiles_dealt if dealt else self._B.lib.rrt_gather_tiles
+        self._B.check(fn(self.h, local.data_ptr(), gathered.data_ptr(), width, height, root, stream))
 
     def close(self):
         if getattr(self, "h", None):
@@ -82,15 +88,16 @@ class TilePipeline:
     next frame's primary kernel); the gather and the de-interleave of the frames run, in frame order, on one
     communication stream behind an event; render i waits for gather i - depth to have read its tile buffer."""
 
-    def __init__(self, scene, width, height, world, device, frame, native=None, depth=3):
+    def __init__(self, scene, width, height, world, device, frame, native=None, depth=3, dealt=False):
         from . import host as H
         self.native = native          # a NativeComm: gather to rank 0 through librrt.so's own RCCL calls
         self._H = H
         self.scene, self.w, self.h, self.world, self.frame = scene, width, height, world, frame
         self.depth = depth
+        self.dealt = bool(dealt) and world > 1      # the settings passed to step() must carry tile_deal = 1 then
         self.local, self.gathered = [], []
         for _ in range(depth):
-            lo, ga = alloc_tile_buffers(width, height, world, device)
+            lo, ga = alloc_tile_buffers(width, height, world, device, self.dealt)
             self.local.append(lo)
             self.gathered.append(ga)
         self.s_render = [torch.cuda.Stream(device=device) for _ in range(depth)]
@@ -109,11 +116,11 @@ class TilePipeline:
         with torch.cuda.stream(self.s_comm):
             self.s_comm.wait_event(self.ev_render[k])
             if self.native is not None:
-                self.native.gather(self.local[k], self.gathered[k], self.w, self.h, root=-1, stream=self.s_comm.cuda_stream)
+                self.native.gather(self.local[k], self.gathered[k], self.w, self.h, root=-1, stream=self.s_comm.cuda_stream, dealt=self.dealt)
             else:
                 gather_tiles(self.local[k], self.gathered[k])
             self._H.assemble_tiles(self.gathered[k].data_ptr(), self.w, self.h, self.world, self.frame.data_ptr(),
-                                   stream=self.s_comm.cuda_stream)
+                                   stream=self.s_comm.cuda_stream, dealt=self.dealt)
             self.ev_comm[k].record(self.s_comm)
         self.i += 1
 

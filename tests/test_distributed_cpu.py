@@ -98,3 +98,51 @@ def test_tile_skew_matches_the_library(H):
         for world in (1, 2, 3, 4, 6, 8):
             assert B.lib.rrt_tile_skew(w, world) == tiles.tile_skew(tiles.tile_grid(w, 8)[0], world), (w, world)
     assert tiles.tile_skew(60, 8) == 1 and tiles.tile_skew(60, 1) == 0
+
+
+def _worker_dealt(rank, world, port, frame, classes, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rustraytracer_amd import distributed as D, tiles
+        h, w = frame.shape[:2]
+        tables = tiles.deal_by_class(classes, world)            # every rank computes the same deal from the same classes
+        local, gathered = D.alloc_tile_buffers(w, h, world, "cpu", dealt=True)
+        local.copy_(torch.from_numpy(tiles.extract_rank_tiles_dealt(frame, tables[rank], w, h, world)))
+        D.gather_tiles(local, gathered)
+        out = tiles.assemble_dealt_numpy(gathered.numpy(), w, h, world)
+        q.put((rank, bool(np.array_equal(out, frame)), None, None))
+    except Exception as e:
+        q.put((rank, False, repr(e), None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size", [(2, (100, 75)), (3, (333, 49))])
+def test_dealt_tile_gather_over_gloo(O, scenes, world, size):
+    """tile_deal = 1 over gloo: the tiles are dealt by a cost class (here: a synthetic one), every rank's buffer carries
+    its own slot -> tile table behind the pixels, and the gathered bytes alone rebuild the frame."""
+    from rustraytracer_amd import tiles
+    w, h = size
+    frame = scenes.cfg1_scene(O.OracleScene(), O).render(w, h, n_threads=2, want=("rgb",))["rgb"]
+    tx, ty = tiles.tile_grid(w, h)
+    classes = np.random.default_rng(3).integers(0, 3, tx * ty)
+    tables = tiles.deal_by_class(classes, world)
+    owned = np.sort(tables[tables >= 0])
+    assert np.array_equal(owned, np.arange(tx * ty))                      # a partition of the image's tiles
+    for c in range(3):                                                   # every rank gets its share of every class
+        per_rank = [(classes[t[t >= 0]] == c).sum() for t in tables]
+        assert max(per_rank) - min(per_rank) <= 2          # (a class may begin and end in the middle of a round)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dealt, args=(r, world, port, frame, classes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res

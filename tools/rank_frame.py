@@ -16,7 +16,9 @@ w.commit()
 w.set_timing(int(os.environ.get('TIMING', '2')))
 dev = torch.device("cuda", 0)
 local, _ = D.alloc_tile_buffers(1920, 1080, world, dev)
-st = H.make_settings(1920, 1080, spp=64, tile_rank=rank, tile_world=world)
+deal = int(os.environ.get("DEAL", "1")) if world > 1 else 0
+local, _ = D.alloc_tile_buffers(1920, 1080, world, dev, dealt=bool(deal))
+st = H.make_settings(1920, 1080, spp=64, tile_rank=rank, tile_world=world, tile_deal=deal)
 for _ in range(3):
     w.render_device(st, local.data_ptr())
 torch.cuda.synchronize()

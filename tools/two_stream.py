@@ -19,11 +19,12 @@ w.commit()
 w.set_timing(0)
 for i in range(4):
     if world > 1:
-        bufs.append(D.alloc_tile_buffers(1920, 1080, world, dev)[0])
+        bufs.append(D.alloc_tile_buffers(1920, 1080, world, dev, dealt=int(os.environ.get("DEAL", "1")) != 0)[0])
     else:
         bufs.append(torch.empty(1080 * 1920 * 3, dtype=torch.uint8, device=dev))
     streams.append(torch.cuda.Stream(device=dev))
-st = H.make_settings(1920, 1080, spp=spp, tile_rank=2 % world, tile_world=world)
+deal = int(os.environ.get("DEAL", "1")) if world > 1 else 0
+st = H.make_settings(1920, 1080, spp=spp, tile_rank=int(os.environ.get("RANK_", "2")) % world, tile_world=world, tile_deal=deal)
 
 
 def run(n_streams):
