@@ -32,7 +32,7 @@ Metric: Mrays/s, whole job.  A ray = one world-level closest-hit query (one
 reference semantics (prune_zero_mix = 0: the reflection ray is cast even when
 its mix is 0.0, as src/tracer.rs:195-201 does).
 
-Frames in flight: steps are enqueued round-robin on `--in-flight` streams (default 4; the scene keeps one set of work
+Frames in flight: steps are enqueued round-robin on `--in-flight` streams (default 4, 3 for frames under a million paths; the scene keeps one set of work
 buffers per stream), so the thin tail of one frame's launch chain (bounce levels, accumulate) runs under the next
 frame's primary kernel.  Every step is a complete frame; `value` is the throughput of K of them.  The figure with one
 frame at a time (the latency of a frame) is printed beside it (`one_frame_at_a_time`), and the per-kernel durations
@@ -96,7 +96,7 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=0, help="override the config's samples per pixel")
     ap.add_argument("--budget-gib", type=float, default=0.0, help="work-buffer budget in GiB (0 = library default)")
     ap.add_argument("--cull-mode", type=int, default=-1, help="rrt_set_cull_mode (0 off, 1 on, 2 verify; -1 = library default)")
-    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("RRT_FRAMES_IN_FLIGHT", "4")),
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("RRT_FRAMES_IN_FLIGHT", "0")),
                     help="frames in flight (one stream and one set of work buffers each); 1 = one frame at a time")
     return ap.parse_args()
 
@@ -287,6 +287,10 @@ def main():
     scene.commit()                                   # scene resident in HBM before timing
 
     frame = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+    if args.in_flight <= 0:
+        # 4 frames in flight; 3 for frames of under a million paths, whose launches the host cannot feed to four
+        # streams any faster (cube + 3 spheres, 640x480: 0.038 ms a frame with 3 in flight, 0.050 with 4)
+        args.in_flight = 4 if w * h * spp0 >= (1 << 20) else 3
     depth = max(1, min(args.in_flight, 4))
     frames = [frame] + [torch.empty_like(frame) for _ in range(depth - 1)] if world == 1 else [frame]
     streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]

@@ -267,6 +267,7 @@ struct DFrame {
     const int32_t* order;
     const uint32_t* list_n;
     uint32_t chunks_per_block;   // 256-path chunks a persistent block of the primary kernel is sized for
+    uint32_t bounce_rays_per_block;   // a bounce level's rays per working block (k_wave_bounce picks how many of its blocks work)
     uint32_t seg_grid;           // grid the batch's primary kernel is launched with (primary_grid): the queue segments follow from it
 };
 

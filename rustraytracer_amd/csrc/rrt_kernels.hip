@@ -2064,7 +2064,7 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     const uint32_t n_seg = L.grid;
     const uint2_* seg_in = wk.seg_n + (size_t)(bounce & 1u) * kMaxSegs;
     uint2_* seg_out = wk.seg_n + (size_t)((bounce + 1u) & 1u) * kMaxSegs;
-    // This block's segments sg_i = blockIdx.x + i * gridDim.x (at most kSegPerBlock of them: launch_bounce sizes the
+    // This block's segments sg_i = blockIdx.x + i * grid (at most kSegPerBlock of them: launch_bounce sizes the
     // grid) are treated as ONE region, their concatenation in the order i = 0, 1, ...: the live rays of all of them
     // form one sequence that is cut into units of 64 (then the dead rays likewise), whatever segment a ray sits in,
     // and the continuation rays go to the front (live) and the back (dead) of the concatenation of the same segments
@@ -2080,11 +2080,32 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     RRT_LDS uint32_t* s_cpre = s_dpre + kSegPerBlock + 1;          // [kSegPerBlock + 1] entries (capacity) ...
     RRT_LDS uint32_t* s_start = s_cpre + kSegPerBlock + 1;         // [kSegPerBlock] first entry of segment i
     RRT_LDS uint32_t* s_cap = s_start + kSegPerBlock;              // [kSegPerBlock]
-    const uint32_t my_nseg = blockIdx.x < n_seg ? (n_seg - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
-    if (wk.q_count[bounce] == 0ull) return;        // a level without rays (grid-uniform): nothing is read, nothing written
+    // The blocks that work: a level with few rays is left to the first `grid` blocks of the launch (its ray count is
+    // known from the level before; about fr.bounce_rays_per_block rays each, at least so many that none takes more than
+    // kSegPerBlock segments, a multiple of 8 so that a segment stays on the XCD that filled it), the others leave on
+    // this one load.  Every block pays the LDS staging (2.3 us of a wave slot): a rank's eighth of the 64-spp frame in
+    // 3 x 2048 staged blocks held 1.67 x the wave-cycles of an eighth of the whole frame's bounce kernels.
+    const unsigned long long level_rays = wk.q_count[bounce];
+    if (level_rays == 0ull) return;                // a level without rays (grid-uniform): nothing is read, nothing written
+    uint32_t grid = gridDim.x;
+    {
+        // ... but never fewer than fill the chip once (1024), and every block of the launch for a level that cannot
+        // give each of those a 64-ray unit per wave: such a level lasts as long as its slowest wave, and a wave with
+        // a handful of rays (a segment's worth) is through sooner than one with 64 that diverge (cube + 3 spheres,
+        // 640x480: 0.097 ms a frame with every block, 0.134 with full units on a fifth of them)
+        unsigned long long want = level_rays / fr.bounce_rays_per_block + 1ull;
+        if (want < 1024ull) want = level_rays < 1024ull * 256ull ? (unsigned long long)grid : 1024ull;
+        const uint32_t need = (n_seg + kSegPerBlock - 1u) / kSegPerBlock;      // <= gridDim.x (launch_bounce)
+        uint32_t g = want < (unsigned long long)grid ? (uint32_t)want : grid;
+        if (g < need) g = need;
+        g = (g + 7u) & ~7u;
+        if (g < grid) grid = g;
+    }
+    if (blockIdx.x >= grid) return;
+    const uint32_t my_nseg = blockIdx.x < n_seg ? (n_seg - blockIdx.x + grid - 1u) / grid : 0u;
     if (threadIdx.x < kSegPerBlock) {
         uint2_ c{0u, 0u};
-        if (threadIdx.x < my_nseg) c = seg_in[blockIdx.x + threadIdx.x * gridDim.x];
+        if (threadIdx.x < my_nseg) c = seg_in[blockIdx.x + threadIdx.x * grid];
         s_live[threadIdx.x] = c.x;
         s_dead[threadIdx.x] = c.y;
     }
@@ -2092,13 +2113,13 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     uint32_t mine = 0u, mine_dead = 0u;
     for (uint32_t i = 0; i < my_nseg; ++i) { mine += s_live[i] + s_dead[i]; mine_dead += s_dead[i]; }
     if (mine == 0u) {       // block-uniform: no rays here; the next level is told so, and the staging is skipped
-        if (threadIdx.x < my_nseg) seg_out[blockIdx.x + threadIdx.x * gridDim.x] = uint2_{0u, 0u};
+        if (threadIdx.x < my_nseg) seg_out[blockIdx.x + threadIdx.x * grid] = uint2_{0u, 0u};
         return;
     }
     if (threadIdx.x < kSegPerBlock) {
         uint32_t st = 0u, cp = 0u;
         if (threadIdx.x < my_nseg) {
-            const SegRange R = seg_range(L, fr.ns, blockIdx.x + threadIdx.x * gridDim.x);
+            const SegRange R = seg_range(L, fr.ns, blockIdx.x + threadIdx.x * grid);
             st = R.start; cp = R.cap;
         }
         s_start[threadIdx.x] = st;
@@ -2201,7 +2222,10 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     }
     // The region is done when all four waves are.  Its continuation rays fill the concatenation from the front (live)
     // and from the back (dead): what that leaves in segment i -- a run at its front, a run at its back -- are its two
-    // counts for the next level.
+    // counts for the next level.  (Measured and dropped: no barrier here, the wave that finishes last -- a counter in
+    // LDS tells -- does this and the others leave at once: 12 % fewer wave-cycles in a rank's bounce kernels, no
+    // change in frame time.)
+    if (bounce == 1u) { TADD(0, acc_q); TADD(1, acc_p); TADD(2, acc_n); TADD(3, TSTAMP() - tk0); TADD(4, 1); TADD(5, acc_dp); TADD(6, acc_dn); TADD(7, acc_lc); }
     __syncthreads();
     if (threadIdx.x < my_nseg) {
         const unsigned long long c = *s_cnt;
@@ -2211,10 +2235,9 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
         const uint32_t d0 = total - td;                                    // dead entries: [d0, total) of the concatenation
         const uint32_t lo = d0 > c0 ? d0 : c0;
         const uint32_t dead_i = c1 > lo ? c1 - lo : 0u;
-        seg_out[blockIdx.x + threadIdx.x * gridDim.x] = uint2_{live_i, dead_i};
+        seg_out[blockIdx.x + threadIdx.x * grid] = uint2_{live_i, dead_i};
         if (threadIdx.x == 0 && tl + td != 0u) atomicAdd(&wk.q_count[bounce + 1u], (unsigned long long)tl + td);
     }
-    if (bounce == 1u) { TADD(0, acc_q); TADD(1, acc_p); TADD(2, acc_n); TADD(3, TSTAMP() - tk0); TADD(4, 1); TADD(5, acc_dp); TADD(6, acc_dn); TADD(7, acc_lc); }
 }
 
 // mean = sum / spp ; vec_rgb (common.rs:75-81); row-major frame or this rank's compact tile buffer
@@ -2732,7 +2755,10 @@ void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t
     uint32_t grid = bounce_grid();
     const uint32_t need = (fr.seg_grid + kSegPerBlock - 1u) / kSegPerBlock;      // a block takes at most kSegPerBlock segments
     if (grid < need) grid = (need + 7u) / 8u * 8u;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, bounce);
+    static const uint32_t rpb = [] { const char* e = getenv("RRT_BOUNCE_RPB"); const long v = e ? atol(e) : 0; return (uint32_t)(v > 0 ? v : 2048); }();
+    DFrame f = fr;
+    f.bounce_rays_per_block = rpb;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, f, bounce);
 }
 void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream,
                        uint32_t tile0, uint32_t n_tiles) {

@@ -17,7 +17,8 @@ bufs, streams = [], []
 w = getattr(scenes, cfg + "_scene")(H.World(device=0), H.loaders)
 w.commit()
 w.set_timing(0)
-for i in range(4):
+NS = [int(x) for x in os.environ.get('NSTREAMS', '1,2,3,4').split(',')]
+for i in range(max(NS)):
     if world > 1:
         bufs.append(D.alloc_tile_buffers(1920, 1080, world, dev, dealt=int(os.environ.get("DEAL", "1")) != 0)[0])
     else:
@@ -28,7 +29,7 @@ st = H.make_settings(1920, 1080, spp=spp, tile_rank=int(os.environ.get("RANK_", 
 
 
 def run(n_streams):
-    for f in range(4):
+    for f in range(2 * n_streams):
         w.render_device(st, bufs[f % n_streams].data_ptr(), stream=streams[f % n_streams].cuda_stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -39,7 +40,7 @@ def run(n_streams):
 
 
 for rep in range(2):
-    t = [run(n) for n in (1, 2, 3, 4)]
-    print("world %d spp %d %s: ms/frame with 1..4 frames in flight: %s" % (world, spp, cfg, " ".join("%.3f" % x for x in t)))
+    t = [run(n) for n in NS]
+    print("world %d spp %d %s: ms/frame with %s frames in flight: %s" % (world, spp, cfg, NS, " ".join("%.3f" % x for x in t)))
 for b in bufs[1:]:
     assert torch.equal(bufs[0], b)
