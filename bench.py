@@ -242,6 +242,14 @@ def attach_profiles(roof, config):
                     roof["issue_floor_frac"] = roof["issue_floor_ms"] / roof["launch_ms"]
         except (ValueError, KeyError):
             pass
+    gf = os.path.join(ROOT, "profiles", "ta_busy%s.json" % sfx)
+    if os.path.exists(gf):
+        try:
+            g = json.load(open(gf)).get("k_wave_primary")
+            if g:
+                roof["gather"] = g
+        except (ValueError, KeyError):
+            pass
     return traffic
 
 
@@ -549,19 +557,31 @@ def main():
                 roof["hbm"] = {"achieved": hbm, "peak": PEAK_HBM_GBS, "frac": hbm / PEAK_HBM_GBS, "unit": "GB/s",
                                "bytes_per_ray": io_b, "algorithmic_bytes_per_launch": io_b * rays_per_launch, "traffic": traffic}
             else:
-                roof.update({"bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS, "traffic": traffic})
+                # configs[4] (2 M-triangle height field): SURVEY 8(d) guessed HBM; the counters say otherwise (11.7 GB per
+                # launch = 0.03 of the HBM peak, L1 hit 98 %).  A ray's walk is a chain of ~80 dependent per-lane gathers:
+                # the bound the counters name is GATHER ISSUE -- busy cycles of the 256 texture-address units over the
+                # cycles of the launch (rocprofv3 --pmc TA_TA_BUSY_sum / GRBM_GUI_ACTIVE, profiles/ta_busy_cfg5.json, of
+                # the previous collection; live figures: avg_launch_ms).  The HBM formula of BASELINE.md section 3 rides
+                # along as a sub-field (bytes if nothing were reused), with the measured traffic beside it.
+                g = roof.pop("gather", None)
+                roof.update({"bound": "gather_issue", "unit": "TA-busy cycles per launch (256 units)", "traffic": traffic,
+                             "achieved": g["ta_busy_cycles"] if g else None, "peak": g["ta_units"] * g["launch_cycles"] if g else None,
+                             "frac": g["frac"] if g else None,
+                             "gather_wave_instructions": g["gather_wave_instructions"] if g else None,
+                             "gather_source": ("profiles/ta_busy_cfg5.json: " + g["source"]) if g else None})
                 if per:
                     tb = traversal_bytes_per_ray(per)
                     ach = (io_b + tb) * rays_per_launch / secs / 1e9
-                    roof.update({"achieved": ach, "frac": ach / PEAK_HBM_GBS, "bytes_per_ray": io_b + tb,
-                                 "io_bytes_per_ray": io_b, "traversal_bytes_per_ray": tb, "per_primary_ray": per,
-                                 "algorithmic_bytes_per_launch": (io_b + tb) * rays_per_launch,
-                                 "formula": "B_io + N_node*16 + N_leaf*128 + N_tri*24 + N_tri_box_hit*72 + hit*32 (BASELINE.md section 3)"})
+                    roof["hbm"] = {"formula_GBps_if_nothing_were_reused": ach, "achieved": (traffic / secs / 1e9) if traffic else None,
+                                   "peak": PEAK_HBM_GBS, "frac": (traffic / secs / 1e9 / PEAK_HBM_GBS) if traffic else None, "unit": "GB/s",
+                                   "bytes_per_ray": io_b + tb, "io_bytes_per_ray": io_b, "traversal_bytes_per_ray": tb,
+                                   "algorithmic_bytes_per_launch": (io_b + tb) * rays_per_launch, "traffic": traffic,
+                                   "formula": "B_io + N_node*16 + N_leaf*128 + N_tri*24 + N_tri_box_hit*72 + hit*32 (BASELINE.md section 3)",
+                                   "note": "achieved/frac = MEASURED HBM traffic over the launch (the formula's bytes are served by L1/L2/MALL)"}
+                    roof["per_primary_ray"] = per
                     fl = flops_per_ray(per)
                     roof["valu_f64"] = {"achieved": fl * rays_per_launch / secs / 1e12, "peak": PEAK_F64_TFLOPS,
                                         "frac": fl * rays_per_launch / secs / 1e12 / PEAK_F64_TFLOPS, "flops_per_ray": fl}
-                else:
-                    roof.update({"achieved": None, "frac": None})
             line["roofline"] = roof
         print(json.dumps(line), flush=True)
     if world > 1:

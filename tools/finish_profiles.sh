@@ -30,6 +30,7 @@ cp gpurun_out/${T}_sq_summary.txt profiles/${T}_sq_summary.txt
 cp gpurun_out/${T}_tcp.txt profiles/counters/${T}_tcp.txt
 test -s profiles/counters/${T}_tcp.txt || { echo "empty TCP summary"; exit 1; }
 python3 tools/valu_busy.py gpurun_out/sq_$T profiles/${T}_kernel_stats.csv > profiles/valu_busy${SFX}.json
+python3 tools/ta_busy.py gpurun_out/tcp_$T > profiles/ta_busy${SFX}.json
 for C in FETCH_SIZE WRITE_SIZE; do
   f=$(find gpurun_out/pmc_$T/$C -name "*counter_collection.csv" | head -1)
   python3 - "$f" profiles/${T}_pmc_$C.csv <<'PY'
@@ -50,8 +51,15 @@ d = json.load(open(f))
 t = json.load(open("profiles/pmc_traffic%s.json" % sfx)).get("k_wave_primary")
 v = json.load(open("profiles/valu_busy%s.json" % sfx)).get("k_wave_primary")
 r = d["roofline"]
+ta = json.load(open("profiles/ta_busy%s.json" % sfx)).get("k_wave_primary")
+if ta and r.get("bound") == "gather_issue":
+    r.update({"achieved": ta["ta_busy_cycles"], "peak": ta["ta_units"] * ta["launch_cycles"], "frac": ta["frac"],
+              "gather_wave_instructions": ta["gather_wave_instructions"], "gather_source": "profiles/ta_busy%s.json: %s" % (sfx, ta.get("source"))})
 if t:
     r["traffic"] = t["hbm_bytes_per_launch"]
+    if r.get("bound") == "gather_issue" and "hbm" in r:
+        gbps = t["hbm_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9
+        r["hbm"].update({"achieved": gbps, "frac": gbps / r["hbm"]["peak"]})
     if "hbm" in r: r["hbm"]["traffic"] = t["hbm_bytes_per_launch"]
     r["traffic_source"] = "profiles/pmc_traffic%s.json: %s" % (sfx, t.get("source"))
 if v:
