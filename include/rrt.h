@@ -179,8 +179,10 @@ int rrt_add_triangle(rrt_scene* s, const double v0[3], const double v1[3], const
  * the group's kd-tree over their bounding boxes (KDTree<T>::new over entities, kdtree.rs:46-51),
  * whose collide (kdtree.rs:192-235) answers with the closest member of the first leaf in which
  * any member is hit -- after the tree's root box passed aabb.rs:50-100, so results can differ from
- * the flat entity loop exactly as they do in the reference.  Groups do not nest.  Entity ids
- * reported in the id AOV remain those of the members.  The group's `position` argument is stored
+ * the flat entity loop exactly as they do in the reference.  A member may itself be a group (Scene<T> is generic over
+ * any Entity, Scene<...> included, scene.rs:32,50-62: its bounding box is its own tree's root box, its collide its own
+ * walk) -- one level deep: a member group may not hold groups (RRT_E_INVALID).  Entity ids
+ * reported in the id AOV remain those of the innermost members.  The group's `position` argument is stored
  * by the reference but never read by render; it is not part of this call.
  * Returns the group's entity id. */
 int rrt_add_group(rrt_scene* s, const int32_t* members, int32_t n_members);

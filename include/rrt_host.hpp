@@ -8,6 +8,7 @@
 #pragma once
 #include <chrono>
 #include <cstdio>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <variant>
@@ -65,10 +66,15 @@ struct Triangle {                                // triangle.rs:19-23: an Entity
 // `entity_enum!(SceneType, Sphere, Model)` is exactly std::variant<Sphere, Model>, and the derived
 // `match self { V(a) => a.collide(ray) }` forwarding is what the kernels do on the entity kind.
 //     Scene::new_(Point3{0,0,0}, {Model(burger), Sphere(sphere), Sphere(sphere2)})   main.rs:57-58
+// A Scene is an Entity too (scene.rs:50-75), so Scene<Scene<...>> is a legal member type: SceneBox carries one
+// (one level deep on the GPU: a member scene may not hold scenes itself).
+struct Scene;
+struct SceneBox { std::shared_ptr<const Scene> scene; };
 struct Scene {
-    using Member = std::variant<Sphere, Model, Triangle>;
+    using Member = std::variant<Sphere, Model, Triangle, SceneBox>;
     std::vector<Member> models; Point3 position;
     static Scene new_(Point3 position, std::vector<Member> models) { return Scene{std::move(models), position}; }
+    SceneBox boxed() const { return SceneBox{std::make_shared<const Scene>(*this)}; }
 };
 
 // lighting.rs:19-32
@@ -119,6 +125,7 @@ class World {
     }
     // world.entities.push(scene)                main.rs:59: the members are reachable through the
     // scene's kd-tree only (rrt_add_group); returns the scene's entity id
+    int push(const SceneBox& b) { return push(*b.scene); }
     int push(const Scene& sc) {
         std::vector<int32_t> ids;
         for (const Scene::Member& m : sc.models)

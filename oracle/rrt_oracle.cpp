@@ -586,10 +586,13 @@ inline Collide group_collide(const Scene& sc, const Group& g, const Ray& ray, in
         Collide best; int best_ent = -1;
         for (int k : leaf->leaf) {
             const int e = g.members[(size_t)k];
-            const Collide r = entity_collide(sc, e, ray, c);
+            // a member may be a Scene<T> itself (scene.rs:32 is generic over any Entity): its collide() is this function
+            int who = e;
+            const Collide r = sc.ents[e].kind == 2 ? group_collide(sc, *sc.groups[sc.ents[e].index], ray, &who, c)
+                                                   : entity_collide(sc, e, ray, c);
             if (r.hit) {
                 const double dist = mag2(sub(r.pos, ray.o));
-                if (dist < min_d) { min_d = dist; best = r; best_ent = e; }
+                if (dist < min_d) { min_d = dist; best = r; best_ent = who; }
             }
         }
         if (best.hit) { *member_out = best_ent; return best; }
@@ -873,7 +876,7 @@ int orc_add_group(void* h, const int32_t* members, int n) {
     auto g = std::make_unique<Group>();
     for (int i = 0; i < n; ++i) {
         const int e = members[i];
-        if (e < 0 || e >= (int)s->ents.size() || s->ents[e].kind == 2 || s->ents[e].parent >= 0) return -1;
+        if (e < 0 || e >= (int)s->ents.size() || s->ents[e].parent >= 0) return -1;
         for (int j = 0; j < i; ++j) if (members[j] == e) return -1;
         AABB b;
         if (s->ents[e].kind == 0) {                       // sphere.rs:49-54
@@ -881,6 +884,8 @@ int orc_add_group(void* h, const int32_t* members, int n) {
             b = AABB{{sp.c.x - sp.r, sp.c.y - sp.r, sp.c.z - sp.r}, {sp.c.x + sp.r, sp.c.y + sp.r, sp.c.z + sp.r}};
         } else if (s->ents[e].kind == 3) {                // triangle.rs:60-65
             b = s->tri_ents[s->ents[e].index].tri.bbox();
+        } else if (s->ents[e].kind == 2) {                // scene.rs:41,60-62: aa_bb = from_entities(models) = its tree's root box
+            b = s->groups[s->ents[e].index]->root->box;
         } else {                                          // model.rs:68-70: the tree's root box
             b = s->meshes[s->ents[e].index]->root->box;
         }

@@ -426,6 +426,10 @@ int commit(rrt_scene* s) {
     d.n_lights = (int32_t)s->lights.size();
     // the reference's own world: light_sources = [one DirectionalLight] (tracer.rs:55-65) -- or none at all
     d.general_lights = (s->lights.empty() || (s->lights.size() == 1 && s->lights[0].kind == 0)) ? 0 : 1;
+    // a world with nested scenes takes the general instantiations too (the nested walk is compiled only there)
+    for (const auto& g : s->groups)
+        for (int32_t m2 : g->members)
+            if ((s->ents[(size_t)m2].kind & ~rrt::kEntityMember) == 2) d.general_lights = 1;
     d.tri_ents = s->d_tri_ents.as<rrt::DTriEnt>();
     d.n_tri_ents = (int32_t)s->tri_ents.size();
     d.shadow_mode = s->shadow_mode;
@@ -1092,7 +1096,12 @@ int rrt_add_group(rrt_scene* s, const int32_t* members, int32_t n) try {
         const int32_t e = members[i];
         if (e < 0 || e >= (int32_t)s->ents.size()) return fail(RRT_E_INVALID, "unknown entity id in group");
         const rrt::DEntity ent = s->ents[(size_t)e];
-        if (ent.kind != 0 && ent.kind != 1 && ent.kind != 3) return fail(RRT_E_INVALID, "group members must be top-level spheres, meshes or triangles");
+        if (ent.kind != 0 && ent.kind != 1 && ent.kind != 2 && ent.kind != 3)
+            return fail(RRT_E_INVALID, "group members must be top-level spheres, meshes, triangles or groups (not members of another group)");
+        if (ent.kind == 2)     // Scene<Scene<T>> (scene.rs:32): one level of nesting
+            for (int32_t m2 : s->groups[(size_t)ent.index]->members)
+                if ((s->ents[(size_t)m2].kind & ~rrt::kEntityMember) == 2)
+                    return fail(RRT_E_INVALID, "groups nest one level deep (a member group may not hold groups itself)");
         for (int32_t j = 0; j < i; ++j)
             if (members[j] == e) return fail(RRT_E_INVALID, "entity listed twice in group");
         if (ent.kind == 0) {   // Sphere::bounding_box, sphere.rs:49-54
@@ -1101,6 +1110,12 @@ int rrt_add_group(rrt_scene* s, const int32_t* members, int32_t n) try {
             for (int a = 0; a < 3; ++a) {
                 mn[3 * (size_t)i + a] = sp.c[a] - r;
                 mx[3 * (size_t)i + a] = sp.c[a] + r;
+            }
+        } else if (ent.kind == 2) {   // Scene::bounding_box = aa_bb = from_entities(models), scene.rs:38-47,60-62: its tree's root box
+            const rrt::KdTreeFlat& T = s->groups[(size_t)ent.index]->tree;
+            for (int a = 0; a < 3; ++a) {
+                mn[3 * (size_t)i + a] = T.boxes[(size_t)a];
+                mx[3 * (size_t)i + a] = T.boxes[3 + (size_t)a];
             }
         } else if (ent.kind == 3) {   // Triangle::bounding_box, triangle.rs:60-65
             const double* p = &s->tri_verts[9 * (size_t)ent.index];

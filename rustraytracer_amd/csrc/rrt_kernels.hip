@@ -772,7 +772,10 @@ RRT_DEV void entity_collide(const DScene& sc, const DNodeI* lnodes, const RRT_LD
 // Scene<T>::collide (scene.rs:50-52) = KDTree<T>::collide (kdtree.rs:192-235) with whole entities in
 // the leaves: the closest member of the first leaf in which any member answers.  `out` receives
 // that member (its entity id), or ent = -1.
-template <int CULL, bool ANY = false, class LDS = NoLds>
+// NEST (the instantiations that also carry the light list: a world with nested scenes takes those): a member may be a
+// Scene<T> itself (scene.rs:32 is generic over any Entity, itself included) -- one level, DEPTH 0 -> 1.  Its answer is
+// its own collide(), i.e. this function again on the member's tree; the outer leaf compares it like any other member's.
+template <int CULL, bool ANY = false, bool NEST = false, int DEPTH = 0, class LDS = NoLds>
 RRT_DEV void group_collide(const DScene& sc, LDS lds, const DGroup& G, const DNodeI* lnodes, V3 o, V3 d, int32_t medium,
                            Closest* out, unsigned long long* stats, double lim2 = 0.0, uint32_t cov = ~0u, uint64_t ebits = ~0ull) {
     out->dist = kF64Max; out->t = 0.0; out->ent = -1; out->entry = -1;
@@ -809,7 +812,17 @@ RRT_DEV void group_collide(const DScene& sc, LDS lds, const DGroup& G, const DNo
                         if (CULL == 1 && binned) continue;
                         const RRT_LDS uint32_t* rec = lds.ents + eu * kEntRec;
                         DEntity ent = lds_uniform<DEntity>(rec);
-                        ent.kind &= ~kEntityMember;        // 0 sphere, 1 mesh or 3 bare triangle (rrt_add_group admits nothing else)
+                        ent.kind &= ~kEntityMember;        // 0 sphere, 1 mesh, 3 bare triangle; 2 = a nested scene (NEST)
+                        if constexpr (NEST && DEPTH == 0) {
+                            if (ent.kind == 2) {
+                                const DGroup G2 = lds_uniform<DGroup>(rec + 2);
+                                Closest h;
+                                group_collide<CULL, ANY, NEST, 1>(sc, lds, G2, lnodes, o, d, medium, &h, stats, lim2, cov, ebits);
+                                if (CULL == 2 && binned && h.ent >= 0) atomicAdd(&stats[2], 1ull);
+                                if (h.ent >= 0 && h.dist < best.dist) best = h;
+                                continue;
+                            }
+                        }
                         entity_collide<CULL, true, ANY, true>(sc, lnodes, rec, eu, ent, o, d, medium, &best, stats, lim2, cov);
                         if (CULL == 2 && binned && best.ent == eu) atomicAdd(&stats[2], 1ull);
                     }
@@ -817,7 +830,17 @@ RRT_DEV void group_collide(const DScene& sc, LDS lds, const DGroup& G, const DNo
             } else {
                 DEntity ent = sc.ents[e];
                 ent.kind &= ~kEntityMember;
-                entity_collide<CULL, false, ANY, true>(sc, lnodes, nullptr, e, ent, o, d, medium, &best, stats, lim2, cov);   // e differs per lane
+                bool nested = false;
+                if constexpr (NEST && DEPTH == 0) {
+                    if (ent.kind == 2) {
+                        nested = true;
+                        const DGroup G2 = sc.groups[ent.index];
+                        Closest h;
+                        group_collide<CULL, ANY, NEST, 1>(sc, lds, G2, lnodes, o, d, medium, &h, stats, lim2, cov, ebits);
+                        if (h.ent >= 0 && h.dist < best.dist) best = h;
+                    }
+                }
+                if (!nested) entity_collide<CULL, false, ANY, true>(sc, lnodes, nullptr, e, ent, o, d, medium, &best, stats, lim2, cov);   // e differs per lane
             }
             if (ANY && best.dist < lim2) break;
         }
@@ -837,7 +860,7 @@ RRT_DEV void group_collide(const DScene& sc, LDS lds, const DGroup& G, const DNo
 
 // The entity loop of RayTracer::cast (tracer.rs:178-190).  GROUPS: the scene holds Scene<T>
 // entities (kind 2); their members carry kEntityMember and are not in world.entities.
-template <int CULL, bool GROUPS, class LDS>
+template <int CULL, bool GROUPS, bool NEST = false, class LDS>
 RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, Closest* best,
                          unsigned long long* stats, uint32_t cov = ~0u, uint64_t ebits = ~0ull) {
     const DNodeI* lnodes = lds.nodes;
@@ -862,7 +885,7 @@ RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, 
                 if constexpr (LDS::kSmall) G = lds_uniform<DGroup>(rec + 2);
                 else G = sc.groups[ent.index];
                 Closest h;
-                group_collide<CULL, false>(sc, lds, G, lnodes, o, d, medium, &h, stats, 0.0, cov, ebits);
+                group_collide<CULL, false, NEST>(sc, lds, G, lnodes, o, d, medium, &h, stats, 0.0, cov, ebits);
                 if (CULL == 2 && binned && h.ent >= 0) atomicAdd(&stats[2], 1ull);    // a group is binned when all its members are
                 if (h.ent >= 0 && h.dist < best->dist) *best = h;
                 continue;
@@ -877,7 +900,7 @@ RRT_DEV void closest_hit(const DScene& sc, LDS lds, V3 o, V3 d, int32_t medium, 
 // closer than lim2 (squared distance of its position from o)?  Same entity order and Entity::collide semantics as
 // closest_hit; stops at the first occluder.  LITERAL (lighting.rs:77-82 as written): returns true as soon as one
 // entity does NOT collide at all ("visible"), false when every entity collides.
-template <int CULL, bool GROUPS, bool LITERAL, class LDS>
+template <int CULL, bool GROUPS, bool LITERAL, bool NEST = false, class LDS>
 RRT_DEV bool any_hit(const DScene& sc, LDS lds, V3 o, V3 d, double lim2, unsigned long long* stats) {
     const DNodeI* lnodes = lds.nodes;
     for (int32_t e = 0; e < sc.n_ents; ++e) {
@@ -897,7 +920,7 @@ RRT_DEV bool any_hit(const DScene& sc, LDS lds, V3 o, V3 d, double lim2, unsigne
                 DGroup G;
                 if constexpr (LDS::kSmall) G = lds_uniform<DGroup>(rec + 2);
                 else G = sc.groups[ent.index];
-                group_collide<CULL, true>(sc, lds, G, lnodes, o, d, -1, &h, stats, lim2);
+                group_collide<CULL, true, NEST>(sc, lds, G, lnodes, o, d, -1, &h, stats, lim2);
                 if (LITERAL) { if (h.ent < 0) return true; }
                 else if (h.ent >= 0 && h.dist < lim2) return true;
                 continue;
@@ -915,13 +938,13 @@ RRT_DEV bool any_hit(const DScene& sc, LDS lds, V3 o, V3 d, double lim2, unsigne
 // with respect to a shadow test; restated because it is what the code says).  shadow_mode 1 (EXTENSION, see
 // rrt_set_shadow_mode): the surface must face the light, the ray starts at pos + normal*0.3, is normalised, and the
 // light is visible iff nothing is hit closer than the light.
-template <int CULL, bool GROUPS, class LDS>
+template <int CULL, bool GROUPS, bool NEST = false, class LDS>
 RRT_DEV bool point_light_visible(const DScene& sc, LDS lds, V3 lpos, V3 pos, V3 normal, unsigned long long* stats) {
-    if (sc.shadow_mode == 0) return any_hit<CULL, GROUPS, true>(sc, lds, pos, lpos - pos, kF64Max, stats);
+    if (sc.shadow_mode == 0) return any_hit<CULL, GROUPS, true, NEST>(sc, lds, pos, lpos - pos, kF64Max, stats);
     if (!(dot(normal, pos - lpos) < 0.)) return false;
     const V3 o = pos + normal * 0.3;
     const V3 v = lpos - o;
-    return !any_hit<CULL, GROUPS, false>(sc, lds, o, normalize(v), mag2(v), stats);
+    return !any_hit<CULL, GROUPS, false, NEST>(sc, lds, o, normalize(v), mag2(v), stats);
 }
 
 // Rebuilds the ColliderResult of the winning entity: position (sphere.rs:39 / triangle.rs:53),
@@ -1093,7 +1116,7 @@ RRT_DEV void shade_direct(const DScene& sc, LDS lds, const DMaterial& m, V3 d, V
                 lp = Lk.a;
             } else {                                                      // PointLight, lighting.rs:60-84
                 const V3 lpos = ld3(Lk.v);
-                if (!point_light_visible<CULL, GROUPS>(sc, lds, lpos, pos, normal, stats)) continue;
+                if (!point_light_visible<CULL, GROUPS, PL>(sc, lds, lpos, pos, normal, stats)) continue;
                 const V3 dir0 = pos - lpos;
                 const double distance2 = mag2(dir0);
                 dir = normalize(dir0);
@@ -1565,7 +1588,7 @@ RRT_DEV void process_ray(const DScene& sc, LDS lds, const DWork& wk, const DFram
         Closest c;
         CNT(0);
         const unsigned long long tc0 = TSTAMP();
-        closest_hit<CULL, GROUPS>(sc, lds, o, d, medium, &c, wk.stats, cov, ebits);
+        closest_hit<CULL, GROUPS, PL>(sc, lds, o, d, medium, &c, wk.stats, cov, ebits);
         if (RRT_PROBE == 2 && tacc) *tacc += TSTAMP() - tc0;
         (void)tc0;
         Hit h;
@@ -2574,8 +2597,8 @@ __global__ __launch_bounds__(256) void k_bins(DScene sc, BinParams p, const uint
     uint64_t members = 0ull, groups = 0ull;
     for (int32_t e = 0; e < sc.n_ents && e < 64; ++e) {
         const int32_t k = sc.ents[e].kind;
-        if (k & kEntityMember) members |= 1ull << e;
-        else if (k == 2) groups |= 1ull << e;
+        if ((k & ~kEntityMember) == 2) groups |= 1ull << e;          // top-level scenes and scenes that are members of one
+        else if (k & kEntityMember) members |= 1ull << e;
     }
     if ((bits & members) == 0ull && sc.n_ents <= 64) bits &= ~groups;
     if (sc.n_ents < 64) bits &= (1ull << sc.n_ents) - 1ull;      // no entity, no bit: 0 = "only sky behind this tile"
@@ -2604,9 +2627,9 @@ __global__ __launch_bounds__(256) void k_trace_rays(DScene sc, const double* ray
     if (i >= n) return;
     const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
     Closest c;
-    if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, kNoLds, o, d, -1, &c, stats);
-    else if (sc.cull_mode == 1) closest_hit<1, GROUPS>(sc, kNoLds, o, d, -1, &c, stats);
-    else closest_hit<2, GROUPS>(sc, kNoLds, o, d, -1, &c, stats);
+    if (sc.cull_mode == 0) closest_hit<0, GROUPS, GROUPS>(sc, kNoLds, o, d, -1, &c, stats);
+    else if (sc.cull_mode == 1) closest_hit<1, GROUPS, GROUPS>(sc, kNoLds, o, d, -1, &c, stats);
+    else closest_hit<2, GROUPS, GROUPS>(sc, kNoLds, o, d, -1, &c, stats);
     Hit h;
     finish_hit(sc, kNoLds, o, d, c, &h);
     const int32_t e = c.ent;
@@ -2632,9 +2655,9 @@ __global__ __launch_bounds__(256) void k_cast_rays(DScene sc, const double* rays
     V3 col;
     for (;;) {
         Closest c;
-        if (sc.cull_mode == 0) closest_hit<0, GROUPS>(sc, kNoLds, o, d, medium, &c, stats);
-        else if (sc.cull_mode == 1) closest_hit<1, GROUPS>(sc, kNoLds, o, d, medium, &c, stats);
-        else closest_hit<2, GROUPS>(sc, kNoLds, o, d, medium, &c, stats);
+        if (sc.cull_mode == 0) closest_hit<0, GROUPS, GROUPS>(sc, kNoLds, o, d, medium, &c, stats);
+        else if (sc.cull_mode == 1) closest_hit<1, GROUPS, GROUPS>(sc, kNoLds, o, d, medium, &c, stats);
+        else closest_hit<2, GROUPS, GROUPS>(sc, kNoLds, o, d, medium, &c, stats);
         Hit h;
         finish_hit(sc, kNoLds, o, d, c, &h);
         if (!h.hit) { col = sky_color(sc, kNoLds, d); break; }
@@ -2663,9 +2686,9 @@ __global__ __launch_bounds__(256) void k_occluded_rays(DScene sc, const double* 
     const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
     const double lim = lim2[i];
     bool r;
-    if (sc.cull_mode == 0) r = any_hit<0, GROUPS, false>(sc, kNoLds, o, d, lim, stats);
-    else if (sc.cull_mode == 1) r = any_hit<1, GROUPS, false>(sc, kNoLds, o, d, lim, stats);
-    else r = any_hit<2, GROUPS, false>(sc, kNoLds, o, d, lim, stats);
+    if (sc.cull_mode == 0) r = any_hit<0, GROUPS, false, GROUPS>(sc, kNoLds, o, d, lim, stats);
+    else if (sc.cull_mode == 1) r = any_hit<1, GROUPS, false, GROUPS>(sc, kNoLds, o, d, lim, stats);
+    else r = any_hit<2, GROUPS, false, GROUPS>(sc, kNoLds, o, d, lim, stats);
     out[i] = r ? 1 : 0;
 }
 
