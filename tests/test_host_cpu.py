@@ -184,9 +184,17 @@ def test_group_tree_identical_to_oracle(H, O, scenes):
             w.add_group(bad)
     g = w.add_group([1, 2])
     with pytest.raises(B.RrtError, match="top-level"):
-        w.add_group([0, g])
+        w.add_group([1])                      # a member of g already
+    # Scene<Scene<T>>: a group may hold groups, one level deep; the outer tree is built over the inner root boxes
+    so = scenes.main_rs_scene(O.OracleScene(), O)
+    go = so.add_group([1, 2])
+    outer_p, outer_o = w.add_group([0, g]), so.add_group([0, go])
+    assert _trees_equal(so.tree(outer_o), w.tree(outer_p))
+    extra = w.add_sphere((0.0, 0.0, 9.0), 1.0, 0)
+    with pytest.raises(B.RrtError, match="one level"):
+        w.add_group([outer_p, extra])
     with pytest.raises(B.RrtError, match="top-level"):
-        w.add_group([1])
+        w.add_group([g, extra])               # g is a member of the outer group now
 
 
 def test_rope_faces_touch(H):
