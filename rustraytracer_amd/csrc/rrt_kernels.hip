@@ -1243,21 +1243,21 @@ RRT_DEV void ld_rec(double* level_base, uint32_t idx, V3* A, V3* Pm, double* mix
 // counter per level in device memory, and with every wave of the chip adding to the same address -- such atomics
 // are performed one after the other at the memory side -- the primary kernel of the 1080p/64spp frame spent a third
 // of its time (1.25 of 3.64 ms) queueing for them.
+// What a trace kernel carries through a cast to append the continuation ray with: ONE LDS address.  The block's queue
+// table sits there (words): [1] n = segments of the block's region, [2..3] the 64-bit append counter, [kSegCpre + i]
+// entries of the segments before i (i = 0 .. 16; [kSegCpre + 16] = the region's capacity), [kSegStart + i] first
+// queue entry of segment i.  (As six values in registers -- counter address, start, capacity, two table addresses, n --
+// they stayed live across the whole traversal in two kernels that spill scalars as it is.)
+constexpr uint32_t kSegN = 1u, kSegCnt = 2u, kSegCpre = 70u, kSegStart = 87u;
 struct SegOut {
-    RRT_LDS unsigned long long* cnt;   // the block's append counter
-    uint32_t start, cap;               // its region of the queue: one segment (the primary kernel) ...
-    // ... or (the bounce kernel) the concatenation of the block's n segments: cpre[i] = entries of the segments before
-    // i (cpre[n] = cap), starts[i] = first entry of segment i
-    const RRT_LDS uint32_t* cpre;
-    const RRT_LDS uint32_t* starts;
-    uint32_t n;
+    RRT_LDS uint32_t* tab;
 };
 // entry of index j of the region
 RRT_DEV uint32_t seg_entry(const SegOut& seg, uint32_t j) {
-    if (seg.cpre == nullptr) return seg.start + j;
+    const uint32_t n = seg.tab[kSegN];
     uint32_t i = 0u;
-    while (i + 1u < seg.n && j >= seg.cpre[i + 1u]) ++i;
-    return seg.starts[i] + (j - seg.cpre[i]);
+    while (i + 1u < n && j >= seg.tab[kSegCpre + i + 1u]) ++i;
+    return seg.tab[kSegStart + i] + (j - seg.tab[kSegCpre + i]);
 }
 RRT_DEV void queue_slots(RRT_LDS unsigned long long* counter, bool live, bool dead, uint32_t* slot_live, uint32_t* slot_dead) {
     const unsigned long long ml = __ballot(live), md = __ballot(dead);
@@ -1551,11 +1551,11 @@ RRT_DEV uint32_t cover_bits(LDS lds, uint32_t x, uint32_t y) {
 RRT_DEV void enqueue_continuation(const DWork& wk, const SegOut& seg, uint32_t bounce, bool cont, bool zero_mix, V3 ro, V3 rd, uint32_t path,
                                   int32_t medium) {
     uint32_t slot_live, slot_dead;
-    queue_slots(seg.cnt, cont && !zero_mix, cont && zero_mix, &slot_live, &slot_dead);
+    queue_slots((RRT_LDS unsigned long long*)(seg.tab + kSegCnt), cont && !zero_mix, cont && zero_mix, &slot_live, &slot_dead);
     if (cont) {
         // queue entry {o.xyz, d.xyz, (path, medium)}
         double* q = wk.q[(bounce + 1) & 1];
-        const uint32_t slot = seg_entry(seg, zero_mix ? seg.cap - 1u - slot_dead : slot_live);
+        const uint32_t slot = seg_entry(seg, zero_mix ? seg.tab[kSegCpre + 16u] - 1u - slot_dead : slot_live);
         at_rec<f64x2>(q, slot, 0u) = f64x2{ro.x, ro.y};
         at_rec<f64x2>(q, slot, 16u) = f64x2{ro.z, rd.x};
         at_rec<f64x2>(q, slot, 32u) = f64x2{rd.y, rd.z};
@@ -1808,10 +1808,16 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
     const uint32_t n_work = L.n_work;
     const SegRange R = seg_range(L, fr.ns, blockIdx.x);
     extern __shared__ __align__(16) unsigned char smem[];
-    RRT_LDS unsigned long long* seg_cnt = (RRT_LDS unsigned long long*)(smem + lds_layout_bytes(sc));
-    if (threadIdx.x == 0) *seg_cnt = 0ull;
+    RRT_LDS uint32_t* seg_tab = (RRT_LDS uint32_t*)(smem + lds_layout_bytes(sc));
+    RRT_LDS unsigned long long* seg_cnt = (RRT_LDS unsigned long long*)(seg_tab + kSegCnt);
+    if (threadIdx.x == 0) {        // the block's queue table: one segment
+        *seg_cnt = 0ull;
+        seg_tab[kSegN] = 1u;
+        seg_tab[kSegCpre] = 0u; seg_tab[kSegCpre + 1u] = R.cap; seg_tab[kSegCpre + 16u] = R.cap;
+        seg_tab[kSegStart] = R.start;
+    }
     const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, true);      // ends with the barrier that also publishes *seg_cnt
-    const SegOut seg{seg_cnt, R.start, R.cap, nullptr, nullptr, 1u};
+    const SegOut seg{seg_tab};
     // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes the list entries
     // k = x (mod 8), and its blocks walk them tile-major (all samples of a tile back to back, on
     // neighbouring blocks of the same XCD), so what one sample of a tile pulls in -- its leaves and
@@ -1961,7 +1967,9 @@ __global__ __launch_bounds__(1024) void k_lists(DFrame fr, uint64_t mesh_mask, u
     // Classes, dearest first.  dealt: the tiles of the image by the cost estimate of k_bins in kDealClasses steps, then
     // (class kDealClasses) the tiles behind which there is only sky.  not dealt: this rank's slots -- 0 = an entity can
     // be met, 1 = sky only, 2 = padding slot.
-    const uint32_t K = dealt ? kDealClasses + 1u : 3u, sky_class = dealt ? kDealClasses : 1u;
+    // (not dealt: ONE scan -- the padding slots, class 2, are the last slots of the rank by construction and keep
+    // their places behind the valid ones)
+    const uint32_t K = dealt ? kDealClasses + 1u : 2u, sky_class = dealt ? kDealClasses : 1u;
     (void)mesh_mask;
     const auto cls_of = [&](uint32_t i, uint32_t* pos) -> uint32_t {
         // dealt: item i is tile i * scatter mod n_img (scatter coprime to n_img, near 0.618 n_img): inside a class the
@@ -2041,6 +2049,10 @@ __global__ __launch_bounds__(1024) void k_lists(DFrame fr, uint64_t mesh_mask, u
             slot_tile[slot] = -1;
             order[slot] = (int32_t)slot;
         }
+    } else {
+        // padding slots (j * W + r >= n_img): the tail of the slot range, behind the heavy and the sky-only lists
+        const uint32_t n_valid = n_img > r ? (n_img - r + W - 1u) / W : 0u;
+        for (uint32_t slot = n_valid + threadIdx.x; slot < fr.n_slots; slot += blockDim.x) order[slot] = (int32_t)slot;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -2115,7 +2127,10 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
         // ... but never fewer than fill the chip once (1024), and every block of the launch for a level that cannot
         // give each of those a 64-ray unit per wave: such a level lasts as long as its slowest wave, and a wave with
         // a handful of rays (a segment's worth) is through sooner than one with 64 that diverge (cube + 3 spheres,
-        // 640x480: 0.097 ms a frame with every block, 0.134 with full units on a fifth of them)
+        // 640x480: 0.097 ms a frame with every block, 0.134 with full units on a fifth of them).  Measured and dropped:
+        // at most 1024 blocks (one round of resident blocks) for a thin level, with units of 16 or 32 rays so that all
+        // four waves of a block have work -- every thin level got slower (second level of the 16-spp frame 138 ->
+        // 154 us, cfg1 0.097 -> 0.134 ms, cfg3 0.485 -> 0.655 ms).
         unsigned long long want = level_rays / fr.bounce_rays_per_block + 1ull;
         if (want < 1024ull) want = level_rays < 1024ull * 256ull ? (unsigned long long)grid : 1024ull;
         const uint32_t need = (n_seg + kSegPerBlock - 1u) / kSegPerBlock;      // <= gridDim.x (launch_bounce)
@@ -2160,6 +2175,7 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
         }
         s_lpre[kSegPerBlock] = al; s_dpre[kSegPerBlock] = ad; s_cpre[kSegPerBlock] = ac;
         *next_unit = 0u;
+        next_unit[kSegN] = my_nseg;
         *s_cnt = 0ull;
     }
     const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, true);      // ends with the barrier that also publishes the above
@@ -2167,7 +2183,8 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     const uint32_t live_units = (n_live + 63u) >> 6, my_units = live_units + ((n_dead + 63u) >> 6);
     // a block with at most one unit a wave carries its paths to their ends (tail mode, below)
     const bool tail = n_live + n_dead <= kTailBlock;
-    const SegOut seg{s_cnt, 0u, s_cpre[kSegPerBlock], s_cpre, s_start, my_nseg};
+    static_assert(kSegPerBlock == 16u, "the queue table's layout (kSegCpre, kSegStart) is written for 16 segments a block");
+    const SegOut seg{next_unit};       // [1] = my_nseg, [2..3] = s_cnt, [kSegCpre ..] = s_cpre, [kSegStart ..] = s_start
     double* q = wk.q[bounce & 1];
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long tk0 = TSTAMP();
