@@ -1263,16 +1263,28 @@ RRT_DEV void queue_slots(RRT_LDS unsigned long long* counter, bool live, bool de
     const unsigned long long ml = __ballot(live), md = __ballot(dead);
     *slot_live = 0u; *slot_dead = 0u;
     if ((ml | md) == 0ull) return;
-    const uint32_t lane = __lane_id();
+    uint32_t lane;         // made here, every time (hoisted out of a trace kernel's loop it is spilled to scratch)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
     const unsigned long long below = (1ull << lane) - 1ull;
     const int leader = __ffsll((long long)(ml | md)) - 1;
     unsigned long long base = 0ull;
     if ((int)lane == leader)
         base = __hip_atomic_fetch_add(counter, (unsigned long long)__popcll(ml) | ((unsigned long long)__popcll(md) << 32), __ATOMIC_RELAXED,
                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-    const uint32_t blo = (uint32_t)__shfl((int)(uint32_t)base, leader, 64), bhi = (uint32_t)__shfl((int)(uint32_t)(base >> 32), leader, 64);
+    // v_readlane with the (scalar) leader: __shfl would go through ds_bpermute and the lane's own number
+    const uint32_t blo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)base, leader), bhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(base >> 32), leader);
     *slot_live = blo + (uint32_t)__popcll(ml & below);
     *slot_dead = bhi + (uint32_t)__popcll(md & below);
+}
+
+// A value every lane of the wave holds alike, but that arrived through a vector load (a count or a list entry in
+// device memory, a table entry in LDS): moved into an SGPR, so that what is computed from it is scalar arithmetic and
+// -- what matters in kernels that are out of registers -- does not sit in VGPRs across a whole traversal.  (Left in
+// VGPRs, the unit counter's LDS address and the region's two ray counts were spilled to scratch in the bounce kernel
+// and reloaded at the top of every unit, one memory round trip after the other: 14.6 k of a unit's 52 k cycles.)
+RRT_DEV uint32_t wave_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+RRT_DEV unsigned long long wave_uniform64(unsigned long long v) {
+    return ((unsigned long long)wave_uniform((uint32_t)(v >> 32)) << 32) | wave_uniform((uint32_t)v);
 }
 
 // How the primary kernel's launch cuts its chunks into blocks (and so the queues into segments).  host_grid = the grid
@@ -1285,7 +1297,7 @@ struct SegLayout {
 };
 RRT_DEV SegLayout seg_layout(const DFrame& fr) {
     SegLayout L;
-    L.n_work = fr.list_n ? fr.list_n[0] : fr.npx_local >> 8;
+    L.n_work = fr.list_n ? wave_uniform(fr.list_n[0]) : fr.npx_local >> 8;
     L.n_chunks = L.n_work * fr.ns;
     L.grid = fr.seg_grid;
     if (fr.list_n) {
@@ -1487,7 +1499,11 @@ RRT_DEV uint32_t path_of(const DFrame& fr, uint32_t s_local, uint32_t pp) {     
     return ((((s_local & ~sm) | j) * n_tiles + slot) << 8) | t;
 }
 RRT_DEV void path_decode(const DFrame& fr, uint32_t path, uint32_t* s_local, uint32_t* pp) {
-    const uint32_t p = fr.pack_log2, sm = (1u << p) - 1u, n_tiles = fr.npx_local >> 8;
+    const uint32_t p = fr.pack_log2, sm = (1u << p) - 1u;
+    // the divisor passes through an empty volatile asm: otherwise the compiler prepares its f32 reciprocal once per
+    // kernel in VGPRs, spills both to scratch in the trace kernels, and every cast waits for their reload
+    uint32_t n_tiles = fr.npx_local >> 8;
+    asm volatile("" : "+s"(n_tiles));
     const uint32_t chunk = path >> 8, t = path & 255u, sc = chunk / n_tiles, slot = chunk - sc * n_tiles;
     *s_local = (sc & ~sm) | (t & sm);
     *pp = (slot << 8) | ((sc & sm) << (8u - p)) | (t >> p);
@@ -1834,7 +1850,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         }
         // chunk = (sample, tile slot), or with sample packing (sample group and part of the tile, tile slot): see
         // path_of.  Wave-uniform, so the tile's position is scalar arithmetic.
-        const uint32_t slot = fr.order ? (uint32_t)fr.order[kk] : kk;
+        const uint32_t slot = fr.order ? wave_uniform((uint32_t)fr.order[kk]) : kk;
         const uint32_t chunk = s_local * n_tiles + slot;
         const uint32_t path = chunk * 256u + threadIdx.x;
         uint32_t my_t = threadIdx.x;
@@ -1883,7 +1899,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
 // Same chunk geometry and path numbers as k_wave_primary.
 __global__ __launch_bounds__(256) void k_sky(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
     __shared__ __align__(16) unsigned char cmem[kCDoubles * 8];
-    const uint32_t n_heavy = fr.list_n[0], n_sky = fr.list_n[1] - n_heavy;
+    const uint32_t n_heavy = wave_uniform(fr.list_n[0]), n_sky = wave_uniform(fr.list_n[1]) - n_heavy;
     const uint32_t n_chunks = n_sky * fr.ns;
     if (blockIdx.x >= n_chunks) return;
     StagedT<false> lds{nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1894,7 +1910,7 @@ __global__ __launch_bounds__(256) void k_sky(DScene sc, DWork wk, DFrame fr, int
     for (uint32_t m = blockIdx.x; m < n_chunks; m += gridDim.x) {
         const uint32_t k = m / fr.ns;
         uint32_t s_local = m - k * fr.ns;
-        const uint32_t slot = (uint32_t)fr.order[n_heavy + k];
+        const uint32_t slot = wave_uniform((uint32_t)fr.order[n_heavy + k]);
         const uint32_t path = (s_local * n_tiles + slot) * 256u + threadIdx.x;
         uint32_t my_t = threadIdx.x;
         if (fr.pack_log2) {
@@ -2120,7 +2136,7 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     // kSegPerBlock segments, a multiple of 8 so that a segment stays on the XCD that filled it), the others leave on
     // this one load.  Every block pays the LDS staging (2.3 us of a wave slot): a rank's eighth of the 64-spp frame in
     // 3 x 2048 staged blocks held 1.67 x the wave-cycles of an eighth of the whole frame's bounce kernels.
-    const unsigned long long level_rays = wk.q_count[bounce];
+    const unsigned long long level_rays = wave_uniform64(wk.q_count[bounce]);
     if (level_rays == 0ull) return;                // a level without rays (grid-uniform): nothing is read, nothing written
     uint32_t grid = gridDim.x;
     {
@@ -2140,7 +2156,7 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
         if (g < grid) grid = g;
     }
     if (blockIdx.x >= grid) return;
-    const uint32_t my_nseg = blockIdx.x < n_seg ? (n_seg - blockIdx.x + grid - 1u) / grid : 0u;
+    const uint32_t my_nseg = wave_uniform(blockIdx.x < n_seg ? (n_seg - blockIdx.x + grid - 1u) / grid : 0u);
     if (threadIdx.x < kSegPerBlock) {
         uint2_ c{0u, 0u};
         if (threadIdx.x < my_nseg) c = seg_in[blockIdx.x + threadIdx.x * grid];
@@ -2150,6 +2166,7 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     __syncthreads();
     uint32_t mine = 0u, mine_dead = 0u;
     for (uint32_t i = 0; i < my_nseg; ++i) { mine += s_live[i] + s_dead[i]; mine_dead += s_dead[i]; }
+    mine = wave_uniform(mine); mine_dead = wave_uniform(mine_dead);
     if (mine == 0u) {       // block-uniform: no rays here; the next level is told so, and the staging is skipped
         if (threadIdx.x < my_nseg) seg_out[blockIdx.x + threadIdx.x * grid] = uint2_{0u, 0u};
         return;
@@ -2179,14 +2196,19 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
         *s_cnt = 0ull;
     }
     const StagedT<SMALL> lds = stage_scene<SMALL>(sc, fr, smem, true);      // ends with the barrier that also publishes the above
-    const uint32_t n_live = s_lpre[kSegPerBlock], n_dead = s_dpre[kSegPerBlock];
+    const uint32_t n_live = wave_uniform(s_lpre[kSegPerBlock]), n_dead = wave_uniform(s_dpre[kSegPerBlock]);
     const uint32_t live_units = (n_live + 63u) >> 6, my_units = live_units + ((n_dead + 63u) >> 6);
     // a block with at most one unit a wave carries its paths to their ends (tail mode, below)
     const bool tail = n_live + n_dead <= kTailBlock;
     static_assert(kSegPerBlock == 16u, "the queue table's layout (kSegCpre, kSegStart) is written for 16 segments a block");
     const SegOut seg{next_unit};       // [1] = my_nseg, [2..3] = s_cnt, [kSegCpre ..] = s_cpre, [kSegStart ..] = s_start
     double* q = wk.q[bounce & 1];
-    const uint32_t lane = threadIdx.x & 63u;
+    // What the top of the unit loop needs is made anew in every trip from a scalar (the table's LDS offset) and from
+    // the hardware (the lane number), behind volatile asm so that neither is hoisted: hoisted, both were VGPRs that
+    // lived through process_ray, were spilled to scratch, and their reloads -- one in front of the unit grab, one
+    // behind it, each a memory round trip -- stood at the head of every unit.
+    const uint32_t tab_off = wave_uniform(lds_layout_bytes(sc));
+    const uint32_t wave_in_block = wave_uniform(threadIdx.x >> 6);      // so that threadIdx.x need not live through the loop
     const unsigned long long tk0 = TSTAMP();
     unsigned long long acc_q = 0, acc_p = 0, acc_n = 0, acc_dp = 0, acc_dn = 0, acc_lc = 0;
     (void)tk0; (void)acc_q; (void)acc_p; (void)acc_n; (void)acc_dp; (void)acc_dn; (void)acc_lc;
@@ -2194,8 +2216,12 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
       for (;;) {
         const unsigned long long t0 = TSTAMP();
         (void)t0;
+        uint32_t lane, off_s = tab_off;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        asm volatile("" : "+s"(off_s));
+        RRT_LDS uint32_t* unit_ctr = (RRT_LDS uint32_t*)(smem + off_s);
         uint32_t u = 0u;
-        if (lane == 0u) u = __hip_atomic_fetch_add(next_unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lane == 0u) u = __hip_atomic_fetch_add(unit_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
         if (u >= my_units) break;               // wave-uniform; the counter only grows, so every wave gets here
         // unit -> rays: live units count up through the live runs of the segments (each at its segment's front), dead
@@ -2267,16 +2293,18 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     // change in frame time.)
     if (bounce == 1u) { TADD(0, acc_q); TADD(1, acc_p); TADD(2, acc_n); TADD(3, TSTAMP() - tk0); TADD(4, 1); TADD(5, acc_dp); TADD(6, acc_dn); TADD(7, acc_lc); }
     __syncthreads();
-    if (threadIdx.x < my_nseg) {
+    uint32_t tid;          // wave 0's lanes = threads 0 .. 63 (kSegPerBlock <= 64)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid));
+    if (wave_in_block == 0u && tid < my_nseg) {
         const unsigned long long c = *s_cnt;
         const uint32_t tl = (uint32_t)c, td = (uint32_t)(c >> 32), total = s_cpre[kSegPerBlock];
-        const uint32_t c0 = s_cpre[threadIdx.x], c1 = c0 + s_cap[threadIdx.x];
+        const uint32_t c0 = s_cpre[tid], c1 = c0 + s_cap[tid];
         const uint32_t live_i = tl > c0 ? (tl < c1 ? tl - c0 : c1 - c0) : 0u;
         const uint32_t d0 = total - td;                                    // dead entries: [d0, total) of the concatenation
         const uint32_t lo = d0 > c0 ? d0 : c0;
         const uint32_t dead_i = c1 > lo ? c1 - lo : 0u;
-        seg_out[blockIdx.x + threadIdx.x * grid] = uint2_{live_i, dead_i};
-        if (threadIdx.x == 0 && tl + td != 0u) atomicAdd(&wk.q_count[bounce + 1u], (unsigned long long)tl + td);
+        seg_out[blockIdx.x + tid * grid] = uint2_{live_i, dead_i};
+        if (tid == 0u && tl + td != 0u) atomicAdd(&wk.q_count[bounce + 1u], (unsigned long long)tl + td);
     }
 }
 
