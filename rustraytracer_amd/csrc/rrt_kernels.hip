@@ -1852,14 +1852,20 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         // path_of.  Wave-uniform, so the tile's position is scalar arithmetic.
         const uint32_t slot = fr.order ? wave_uniform((uint32_t)fr.order[kk]) : kk;
         const uint32_t chunk = s_local * n_tiles + slot;
-        const uint32_t path = chunk * 256u + threadIdx.x;
-        uint32_t my_t = threadIdx.x;
+        // the thread's number, opaque to the optimiser in every trip: what it would otherwise prepare from it once per
+        // kernel (the lane's part of its record, queue and sample addresses, its place in the tile) are VGPRs that
+        // live through the whole cast -- the record base was spilled to scratch and its reload stood, with a wait for
+        // every store before it, in front of the record's stores
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const uint32_t path = chunk * 256u + tid;
+        uint32_t my_t = tid;
         uint32_t tag_base = s_local * fr.npx_local + (slot << 8);
         if (fr.pack_log2) {
             const uint32_t p = fr.pack_log2, sm = (1u << p) - 1u;
             tag_base = (s_local & ~sm) * fr.npx_local + (slot << 8) + ((s_local & sm) << (8u - p));
-            my_t = ((s_local & sm) << (8u - p)) | (threadIdx.x >> p);
-            s_local = (s_local & ~sm) | (threadIdx.x & sm);
+            my_t = ((s_local & sm) << (8u - p)) | (tid >> p);
+            s_local = (s_local & ~sm) | (tid & sm);
         }
         const uint32_t my_in = tile_swz(my_t);
         uint32_t tx = 0, ty = 0;
