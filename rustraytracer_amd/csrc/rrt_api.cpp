@@ -844,12 +844,8 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     if (pl.want_bins) rrt::launch_bins(s->dscene, fr, stream);
     else if (pl.want_lists) HIP_TRY(hipMemsetAsync(const_cast<uint64_t*>(fr.tile_bins), 0xff, bins_bytes(fr, true), stream));   // dealt, no bins: every tile "can meet everything"
     if (pl.want_lists) {
-        uint64_t mesh_mask = 0;
-        for (size_t e = 0; e < s->ents.size() && e < 64; ++e)
-            if ((s->ents[e].kind & ~rrt::kEntityMember) == 1) mesh_mask |= 1ull << e;
-        if (!pl.want_bins) mesh_mask = ~0ull;
         // cull mode 2 (verify): every tile goes through the wavefront kernels, which check the bins
-        rrt::launch_lists(fr, mesh_mask, pl.dealt, s->cull_mode != 1 || !pl.want_bins, stream);
+        rrt::launch_lists(fr, pl.dealt, s->cull_mode != 1 || !pl.want_bins, stream);
     }
     // The sky-only tiles run beside the wavefront kernels on a stream of their own (RRT_SKY_FORK=0, and the entry
     // point that allocates nothing: in front of them on the same stream).

@@ -299,8 +299,8 @@ void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint
 void launch_cover(const DMesh& mesh, int32_t n_entries, const DFrame& fr, uint32_t slot, void* stream);
 // Fills fr.tile_bins from the scene's spheres and the frame's coverage masks (after launch_cover).
 void launch_bins(const DScene& sc, const DFrame& fr, void* stream);
-// Fills fr.order / fr.list_n (and fr.slot_tile when `dealt`) from fr.tile_bins; mesh_mask = entity bits that are meshes.
-void launch_lists(const DFrame& fr, uint64_t mesh_mask, bool dealt, bool all_heavy, void* stream);
+// Fills fr.order / fr.list_n (and fr.slot_tile when `dealt`) from fr.tile_bins and fr.tile_cost.
+void launch_lists(const DFrame& fr, bool dealt, bool all_heavy, void* stream);
 uint32_t primary_chunks_per_block();
 uint32_t primary_grid(const DFrame& fr);
 // The sky-only slots of the batch (fr.order[list_n[0] .. list_n[1])): texel words into wk.samp32, AOVs of sample 0.

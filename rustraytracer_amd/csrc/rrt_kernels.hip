@@ -47,9 +47,6 @@ namespace {
 #ifndef RRT_XCD_ORDER
 #define RRT_XCD_ORDER 1
 #endif
-#ifndef RRT_EXP_NOATOMIC
-#define RRT_EXP_NOATOMIC 0
-#endif
 #if RRT_PROBE
 __device__ unsigned long long g_phase[32];
 #if RRT_PROBE == 2      // timing only: the event counters' atomics would be what is timed
@@ -1878,7 +1875,7 @@ __global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWor
         // the tile's bin: a 64-bit scalar through the entity loop (parked in LDS and looked up per entity instead, to
         // spare the two SGPRs, it measured slower: cfg2 primary kernel 1.00 against 0.96 ms)
         uint64_t ebits = ~0ull;
-        if (CULL != 0 && fr.tile_bins && tile_ok) ebits = fr.tile_bins[ty * fr.tiles_x + tx];   // scalar load
+        if (CULL != 0 && fr.tile_bins && tile_ok) ebits = wave_uniform64(fr.tile_bins[ty * fr.tiles_x + tx]);   // one word a chunk, into an SGPR pair
         if (active) {
             if (CULL != 0) cov = cover_bits(lds, x, y);       // requested before the ray is generated
             primary_ray(fr, lds, x, y, sample, &o, &d);
@@ -1977,7 +1974,7 @@ RRT_DEV unsigned long long block_exclusive_scan(unsigned long long v, unsigned l
     return base + incl - v;
 }
 constexpr uint32_t kDealClasses = 16u;      // cost classes of the tiles in which an entity can be met (dealt mode)
-__global__ __launch_bounds__(1024) void k_lists(DFrame fr, uint64_t mesh_mask, uint32_t dealt, uint32_t all_heavy, uint32_t scatter,
+__global__ __launch_bounds__(1024) void k_lists(DFrame fr, uint32_t dealt, uint32_t all_heavy, uint32_t scatter,
                                                 int32_t* slot_tile, int32_t* order, uint32_t* list_n) {
     __shared__ unsigned long long wave_tot[16];
     __shared__ uint32_t px_sum;
@@ -1992,7 +1989,6 @@ __global__ __launch_bounds__(1024) void k_lists(DFrame fr, uint64_t mesh_mask, u
     // (not dealt: ONE scan -- the padding slots, class 2, are the last slots of the rank by construction and keep
     // their places behind the valid ones)
     const uint32_t K = dealt ? kDealClasses + 1u : 2u, sky_class = dealt ? kDealClasses : 1u;
-    (void)mesh_mask;
     const auto cls_of = [&](uint32_t i, uint32_t* pos) -> uint32_t {
         // dealt: item i is tile i * scatter mod n_img (scatter coprime to n_img, near 0.618 n_img): inside a class the
         // tiles then follow each other in a scattered order instead of image order -- in image order the rows of a
@@ -2883,7 +2879,7 @@ void launch_bins(const DScene& sc, const DFrame& fr, void* stream) {
     hipLaunchKernelGGL(k_bins, dim3((n + 255u) / 256u), dim3(256), 0, (hipStream_t)stream, sc, p, fr.cover, fr.cover ? fr.n_cover : 0u,
                        fr.cover_stride, fr.cover_bytes, const_cast<uint64_t*>(fr.tile_bins), const_cast<uint8_t*>(fr.tile_cost));
 }
-void launch_lists(const DFrame& fr, uint64_t mesh_mask, bool dealt, bool all_heavy, void* stream) {
+void launch_lists(const DFrame& fr, bool dealt, bool all_heavy, void* stream) {
     uint32_t scatter = 1u;
     if (dealt) {
         const uint32_t n = fr.tiles_x * fr.tiles_y;
@@ -2892,7 +2888,7 @@ void launch_lists(const DFrame& fr, uint64_t mesh_mask, bool dealt, bool all_hea
         while (n > 1u && gcd(scatter % n, n) != 1u) scatter += 2u;
         if (n <= 1u) scatter = 1u;
     }
-    hipLaunchKernelGGL(k_lists, dim3(1), dim3(1024), 0, (hipStream_t)stream, fr, mesh_mask, dealt ? 1u : 0u, all_heavy ? 1u : 0u, scatter,
+    hipLaunchKernelGGL(k_lists, dim3(1), dim3(1024), 0, (hipStream_t)stream, fr, dealt ? 1u : 0u, all_heavy ? 1u : 0u, scatter,
                        const_cast<int32_t*>(fr.slot_tile), const_cast<int32_t*>(fr.order), const_cast<uint32_t*>(fr.list_n));
 }
 void launch_sky(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
