@@ -2422,9 +2422,8 @@ __global__ __launch_bounds__(256) void k_accumulate_quad(DWork wk, DFrame fr, ui
     const uint32_t pp = (lp & ~255u) | tile_unswz(lp & 255u);
     V3 acc = mk(0., 0., 0.);
     if (fr.s0 != 0u) acc = mk(wk.accum[lp], wk.accum[lp + N], wk.accum[lp + 2 * (size_t)N]);
-    for (uint32_t s0 = 0; s0 < fr.ns; s0 += 16u) {
-        const uint32_t p0 = path_of(fr, s0, pp) + 4u * sub;    // samples s0 .. s0 + 15 of a pixel: consecutive paths
-        const uint4 tg = *(const uint4*)(wk.samp32 + p0);
+    // one trip = samples s0 .. s0 + 15 of the pixel (consecutive paths); tg = this lane's four tags of them
+    const auto trip = [&](uint32_t s0, uint32_t p0, uint4 tg) {
         const uint32_t tag[4] = {tg.x, tg.y, tg.z, tg.w};
         V3 v[4];
 #pragma unroll
@@ -2447,6 +2446,25 @@ __global__ __launch_bounds__(256) void k_accumulate_quad(DWork wk, DFrame fr, ui
             // every lane computed "the quad's sum so far + its own four"; lane q's is the one that is in order
             acc = mk(quad_bcast(a.x, q), quad_bcast(a.y, q), quad_bcast(a.z, q));
         }
+    };
+    // The tags of four trips are requested together: a trip is a chain tag -> colour -> sixteen additions, and one
+    // after the other the four trips of a 64-sample batch were eight dependent memory round trips per pixel; a pixel
+    // behind which there is only sky (three of four) has no colours to fetch and is left with one.
+    uint32_t s0 = 0u;
+    for (; s0 + 64u <= fr.ns; s0 += 64u) {
+        uint32_t p0[4];
+        uint4 tg[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            p0[k] = path_of(fr, s0 + 16u * k, pp) + 4u * sub;
+            tg[k] = *(const uint4*)(wk.samp32 + p0[k]);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) trip(s0 + 16u * k, p0[k], tg[k]);
+    }
+    for (; s0 < fr.ns; s0 += 16u) {
+        const uint32_t p0 = path_of(fr, s0, pp) + 4u * sub;
+        trip(s0, p0, *(const uint4*)(wk.samp32 + p0));
     }
     if (sub != 0u) return;
     if (FINAL) {
