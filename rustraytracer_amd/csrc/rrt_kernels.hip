@@ -29,6 +29,13 @@ namespace {
 // that reaches it, 1 to g_phase[2i] and the number of active lanes to g_phase[2i+1]; with the
 // static instruction counts of the blocks in the ISA this gives the issue budget of a frame
 // (tools/phase_probe.py).  The shipped build (RRT_PROBE 0) contains none of this.
+// The library is built from this file as TWO translation units (make -j halves the five minutes of hipcc): RRT_TU 1 =
+// the bounce kernels' launcher, and so their 18 instantiations; RRT_TU 0 = every other launcher and the static scratch.
+// Undefined = everything in one unit (the probe, variant and listing builds).
+#ifndef RRT_TU
+#define RRT_TU -1
+#endif
+#define RRT_TU_HAS(x) (RRT_TU < 0 || RRT_TU == (x))
 #ifndef RRT_WAVES
 #define RRT_WAVES 4   // waves per SIMD the trace kernels are register-bounded for
 #endif
@@ -2813,6 +2820,7 @@ inline size_t lds_bytes(const DScene& sc) { return (size_t)lds_layout_bytes(sc) 
         return c == 0 ? name<0, false, false, false> : c == 1 ? name<1, false, false, false> : name<2, false, false, false>;         \
     }()
 
+#if RRT_TU_HAS(0)
 uint32_t primary_chunks_per_block() {
     static const uint32_t per_block = [] { const char* e = getenv("RRT_CHUNKS_PER_BLOCK"); const long v = e ? atol(e) : 0; return (uint32_t)(v > 0 ? v : 16); }();
     return per_block;
@@ -2838,6 +2846,8 @@ uint32_t primary_grid(const DFrame& fr) {
     if (want >= 8) want -= want % 8;
     return (uint32_t)(want ? want : 1);
 }
+#endif
+#if RRT_TU_HAS(1)
 void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream) {
     auto k = RRT_PICK(k_wave_bounce);
     uint32_t grid = bounce_grid();
@@ -2848,6 +2858,8 @@ void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t
     f.bounce_rays_per_block = rpb;
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, f, bounce);
 }
+#endif
+#if RRT_TU_HAS(0)
 void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream,
                        uint32_t tile0, uint32_t n_tiles) {
     // tile slots [tile0, tile0 + n_tiles) of this rank (n_tiles = 0: all of them).  rrt_render resolves the frame in
@@ -2991,4 +3003,5 @@ void philox4x32_10_host(const uint32_t ctr[4], const uint32_t key[2], uint32_t o
     philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
 }
 
+#endif      // RRT_TU_HAS(0)
 }  // namespace rrt

@@ -1,4 +1,4 @@
-"""VGPR / SGPR counts and spills of the trace kernels: parses the gfx950 code object out of rrt_kernels.o.
+"""VGPR / SGPR counts and spills of the trace kernels: parses the gfx950 code objects out of rrt_kernels_{a,b}.o.
    python tools/spills.py [regex]"""
 import re
 import struct
@@ -7,7 +7,13 @@ import sys
 import tempfile
 
 import os
-obj = open(os.environ.get("OBJ", "rustraytracer_amd/csrc/rrt_kernels.o"), "rb").read()   # OBJ=/tmp/rrt_kernels_<variant>.o
+# the library's kernels are two objects (RRT_TU 0 / 1); OBJ=/tmp/rrt_kernels_<variant>.o for a variant build
+OBJS = os.environ.get("OBJ", "rustraytracer_amd/csrc/rrt_kernels_a.o,rustraytracer_amd/csrc/rrt_kernels_b.o").split(",")
+if len(OBJS) > 1:
+    for o in OBJS:
+        subprocess.run([sys.executable, __file__] + sys.argv[1:], env=dict(os.environ, OBJ=o))
+    sys.exit(0)
+obj = open(OBJS[0], "rb").read()
 magic = b"__CLANG_OFFLOAD_BUNDLE__"
 at = obj.find(magic)
 if at < 0:
