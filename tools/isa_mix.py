@@ -1,4 +1,5 @@
-"""Static instruction mix of one kernel of rrt_kernels.o (gfx950 code object): python tools/isa_mix.py <name regex>"""
+"""Static instruction mix of one kernel of rrt_kernels_a.o / _b.o (gfx950 code objects; OBJ=<file> picks one, default: the
+bounce kernels' object for a name with "bounce" in it, else the other): python tools/isa_mix.py <name regex>"""
 import collections
 import re
 import struct
@@ -6,7 +7,9 @@ import subprocess
 import sys
 import tempfile
 
-obj = open("rustraytracer_amd/csrc/rrt_kernels.o", "rb").read()
+import os
+_default = "rustraytracer_amd/csrc/rrt_kernels_b.o" if len(sys.argv) > 1 and "bounce" in sys.argv[1] else "rustraytracer_amd/csrc/rrt_kernels_a.o"
+obj = open(os.environ.get("OBJ", _default), "rb").read()
 magic = b"__CLANG_OFFLOAD_BUNDLE__"
 at = obj.find(magic)
 n = struct.unpack_from("<Q", obj, at + len(magic))[0]
