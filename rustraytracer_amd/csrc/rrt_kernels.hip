@@ -2149,15 +2149,13 @@ __global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWor
     if (level_rays == 0ull) return;                // a level without rays (grid-uniform): nothing is read, nothing written
     uint32_t grid = gridDim.x;
     {
-        // ... but never fewer than fill the chip once (1024), and every block of the launch for a level that cannot
-        // give each of those a 64-ray unit per wave: such a level lasts as long as its slowest wave, and a wave with
-        // a handful of rays (a segment's worth) is through sooner than one with 64 that diverge (cube + 3 spheres,
-        // 640x480: 0.097 ms a frame with every block, 0.134 with full units on a fifth of them).  Measured and dropped:
-        // at most 1024 blocks (one round of resident blocks) for a thin level, with units of 16 or 32 rays so that all
-        // four waves of a block have work -- every thin level got slower (second level of the 16-spp frame 138 ->
-        // 154 us, cfg1 0.097 -> 0.134 ms, cfg3 0.485 -> 0.655 ms).
+        // ... but never fewer than fill the chip once: 1024 blocks are resident at a time (4 a CU).  A thin level (it
+        // runs in tail mode, below) lasts as long as its slowest wave whatever the block count -- 137 us for the
+        // 55.7 k second-level rays of the 16-spp frame with 1024 as with 2048 blocks -- and fewer blocks stage less.
+        // Measured and dropped: units of 16 or 32 rays for a thin level, so that all four waves of a block have work
+        // (in tail mode every unit is carried to its paths' ends, one after the other: cfg1 0.097 -> 0.134 ms).
         unsigned long long want = level_rays / fr.bounce_rays_per_block + 1ull;
-        if (want < 1024ull) want = level_rays < 1024ull * 256ull ? (unsigned long long)grid : 1024ull;
+        if (want < 1024ull) want = 1024ull;
         const uint32_t need = (n_seg + kSegPerBlock - 1u) / kSegPerBlock;      // <= gridDim.x (launch_bounce)
         uint32_t g = want < (unsigned long long)grid ? (uint32_t)want : grid;
         if (g < need) g = need;
