@@ -160,6 +160,7 @@ struct rrt_scene {
     bool dirty = true;
     DevBuf d_ents, d_spheres, d_meshes, d_mats, d_groups, d_lights, d_tri_ents, d_mesh_stage;
     rrt::DScene dscene{};
+    DevBuf d_dscene;                // the same block in device memory (kernels may take it by pointer: RRT_SC_BY_PTR)
 
     DevBuf w_ids, w_t, w_color, w_rgb;  // staging for the host-output render
     hipStream_t host_stream = nullptr, copy_stream = nullptr;    // rrt_render: its own stream + the one its D2H copies run on
@@ -526,6 +527,7 @@ int commit(rrt_scene* s) {
         const int e = rrt::scratch_base(s->device, &base);
         if (e != 0) return fail(RRT_E_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString((hipError_t)e));
     }
+    HIP_TRY(s->d_dscene.upload(&s->dscene, sizeof(rrt::DScene)));
     s->dirty = false;
     return RRT_OK;
 }
@@ -891,7 +893,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
             tl->launches = 1;
             HIP_TRY(hipEventRecord(tl->a, stream));
         }
-        rrt::launch_primary(s->dscene, wk, fr, (int32_t*)d_ids, (double*)d_t, stream);
+        rrt::launch_primary(s->dscene, s->d_dscene.as<rrt::DScene>(), wk, fr, (int32_t*)d_ids, (double*)d_t, stream);
         if (timed_kernels) {
             HIP_TRY(hipEventRecord(tl->b, stream));
             // one event pair around the batch's bounce levels together (each hipEventRecord between two
@@ -903,7 +905,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
             HIP_TRY(hipEventRecord(tl->a, stream));
         }
         for (uint32_t bounce = 1; bounce <= st->max_bounce + 1; ++bounce)
-            rrt::launch_bounce(s->dscene, wk, fr, bounce, stream);
+            rrt::launch_bounce(s->dscene, s->d_dscene.as<rrt::DScene>(), wk, fr, bounce, stream);
         if (timed_kernels) HIP_TRY(hipEventRecord(tl->b, stream));
         if (fork) HIP_TRY(hipStreamWaitEvent(stream, ws->ev_join, 0));
         const bool last = b + 1 == pl.n_batches;

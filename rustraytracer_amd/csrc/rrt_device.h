@@ -291,8 +291,9 @@ inline uint32_t tile_skew(uint32_t tiles_x, uint32_t world) {
 }
 
 // ---- launchers (rrt_kernels.hip); all asynchronous on `stream` ------------
-void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream);
-void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream);
+// d_sc = the same DScene in device memory (what the kernels read when built with RRT_SC_BY_PTR)
+void launch_primary(const DScene& sc, const DScene* d_sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream);
+void launch_bounce(const DScene& sc, const DScene* d_sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream);
 void launch_accumulate(const DWork& wk, const DFrame& fr, bool final_batch, uint8_t* d_rgb8, double* d_color, void* stream,
                        uint32_t tile0 = 0, uint32_t n_tiles = 0);
 // Fills coverage mask `slot` of fr (zeroed by the caller) from the mesh's triangle stream (n entries).

@@ -36,6 +36,21 @@ namespace {
 #define RRT_TU -1
 #endif
 #define RRT_TU_HAS(x) (RRT_TU < 0 || RRT_TU == (x))
+// Switch (off): the two wavefront kernels take the scene block by pointer (device memory, read through scalar loads)
+// instead of 500 B by value in the kernarg segment.  Measured: SGPR spills 108 -> 107 / 135 -> 127, frame times
+// within noise -- kernargs are fetched by the same s_loads on demand, so nothing but the base address changes.
+#ifndef RRT_SC_BY_PTR
+#define RRT_SC_BY_PTR 0
+#endif
+#if RRT_SC_BY_PTR
+#define RRT_SC_PARAM const DScene* __restrict__ scp
+#define RRT_SC_BIND const DScene& sc = *scp;
+#define RRT_SC_ARG(host, dev) (dev)
+#else
+#define RRT_SC_PARAM DScene sc
+#define RRT_SC_BIND
+#define RRT_SC_ARG(host, dev) (host)
+#endif
 #ifndef RRT_WAVES
 #define RRT_WAVES 4   // waves per SIMD the trace kernels are register-bounded for
 #endif
@@ -1818,7 +1833,8 @@ RRT_DEV StagedT<SMALL> stage_scene(const DScene& sc, const DFrame& fr, unsigned 
 // Persistent blocks: block b takes path tiles b, b + grid, ... (neighbouring tiles, which cost
 // about the same, go to different blocks), so the LDS staging is paid once per block.
 template <int CULL, bool GROUPS, bool SMALL, bool PL>
-__global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(DScene sc, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
+__global__ __launch_bounds__(256, RRT_WAVES) void k_wave_primary(RRT_SC_PARAM, DWork wk, DFrame fr, int32_t* d_ids, double* d_t) {
+    RRT_SC_BIND
     const uint32_t n_tiles = fr.npx_local >> 8;
     // The slots this launch covers: with tile lists only the "heavy" ones (a primary ray through the tile can meet an
     // entity; fr.order lists them first) -- the sky-only slots are k_sky's; without lists every slot.  The host sizes
@@ -2118,7 +2134,8 @@ constexpr uint32_t kSegPerBlock = 16u;      // segments a block of the bounce ke
 // dozen leaves inside it); with one fixed 64-ray slice per wave and round, a block kept its LDS and
 // register slots until its slowest wave was done (measured: 2.4 of 4 waves/SIMD resident).
 template <int CULL, bool GROUPS, bool SMALL, bool PL>
-__global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(DScene sc, DWork wk, DFrame fr, uint32_t bounce) {
+__global__ __launch_bounds__(256, RRT_BWAVES) void k_wave_bounce(RRT_SC_PARAM, DWork wk, DFrame fr, uint32_t bounce) {
+    RRT_SC_BIND
     extern __shared__ __align__(16) unsigned char smem[];
     const SegLayout L = seg_layout(fr);
     const uint32_t n_seg = L.grid;
@@ -2825,7 +2842,8 @@ uint32_t primary_chunks_per_block() {
     static const uint32_t per_block = [] { const char* e = getenv("RRT_CHUNKS_PER_BLOCK"); const long v = e ? atol(e) : 0; return (uint32_t)(v > 0 ? v : 16); }();
     return per_block;
 }
-void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
+void launch_primary(const DScene& sc, const DScene* d_sc, const DWork& wk, const DFrame& fr, int32_t* d_ids, double* d_t, void* stream) {
+    (void)d_sc;
     // About sixteen 256-path chunks per persistent block, in a grid that is a multiple of 8 (the XCD-aware order) and of
     // at least 2048 blocks (a small launch still fills the chip).  Sweeps on the full cfg2 frame (130 k chunks), one
     // frame at a time, before the sky-only arm: 4096 blocks 1.63 ms, 8192 1.51, 16384 1.47, 32768 1.51.  With that arm
@@ -2833,7 +2851,7 @@ void launch_primary(const DScene& sc, const DWork& wk, const DFrame& fr, int32_t
     // 36.1 Grays/s, 8: 35.4, 32: 35.3 (one frame at a time 8 is 2 % ahead).  Height field, 259 k chunks a launch: 16384
     // blocks 57.0 ms, 32768 56.5.
     auto k = RRT_PICK(k_wave_primary);
-    hipLaunchKernelGGL(k, dim3(fr.seg_grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, fr, d_ids, d_t);      // fr.seg_grid = primary_grid(fr)
+    hipLaunchKernelGGL(k, dim3(fr.seg_grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, RRT_SC_ARG(sc, d_sc), wk, fr, d_ids, d_t);      // fr.seg_grid = primary_grid(fr)
 }
 // The primary kernel's grid for a batch (every slot counted; with tile lists the kernel itself uses fewer blocks, see
 // seg_layout).  Also the number of queue segments the bounce kernels may meet: DFrame::seg_grid.
@@ -2848,7 +2866,8 @@ uint32_t primary_grid(const DFrame& fr) {
 }
 #endif
 #if RRT_TU_HAS(1)
-void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream) {
+void launch_bounce(const DScene& sc, const DScene* d_sc, const DWork& wk, const DFrame& fr, uint32_t bounce, void* stream) {
+    (void)d_sc;
     auto k = RRT_PICK(k_wave_bounce);
     uint32_t grid = bounce_grid();
     const uint32_t need = (fr.seg_grid + kSegPerBlock - 1u) / kSegPerBlock;      // a block takes at most kSegPerBlock segments
@@ -2856,7 +2875,7 @@ void launch_bounce(const DScene& sc, const DWork& wk, const DFrame& fr, uint32_t
     static const uint32_t rpb = [] { const char* e = getenv("RRT_BOUNCE_RPB"); const long v = e ? atol(e) : 0; return (uint32_t)(v > 0 ? v : 2048); }();
     DFrame f = fr;
     f.bounce_rays_per_block = rpb;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, sc, wk, f, bounce);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds_bytes(sc), (hipStream_t)stream, RRT_SC_ARG(sc, d_sc), wk, f, bounce);
 }
 #endif
 #if RRT_TU_HAS(0)
