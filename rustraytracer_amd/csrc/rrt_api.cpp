@@ -868,23 +868,40 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
         fr.seg_grid = rrt::primary_grid(fr);
         if (b > 0) HIP_TRY(hipMemsetAsync(wk.q_count, 0, kQCountBytes, stream));
         TimedLaunch* tl = nullptr;
-        if (pl.want_lists) {
+        // Where in the batch's chain the sky kernel forks off: BEHIND the primary kernel.  The sky tiles are off the
+        // frame's critical path (primary kernel -> bounce levels -> accumulate) and the bounce levels leave most of the
+        // chip idle (the first one in its tail, the thin ones throughout): forked in front of the primary kernel
+        // (round 3's first version) the sky kernel shared the chip with it from the start and was done long before
+        // those gaps came.  One frame at a time, 1080p: 16 spp 1.37 -> 1.24 ms (primary kernel 775 -> 622 us, first
+        // bounce level 320 -> 343, the sky kernel inside it), 64 spp 3.84 -> 3.56 ms, a rank's eighth 0.81 -> 0.75;
+        // four frames in flight 3.148 -> 3.120 ms, the eighth 0.486 -> 0.494.  Behind the first bounce level
+        // (RRT_SKY_AFTER=2) the sky kernel is longer than what is left of the chain: 3.77 ms, in flight 3.24.
+        // RRT_SKY_AFTER=0: in front of the primary kernel.
+        static const int sky_after_env = [] { const char* e = getenv("RRT_SKY_AFTER"); return e ? atoi(e) : 1; }();
+        const int sky_after = fork ? sky_after_env : 0;
+        auto sky = [&]() -> int {
             // (the sky kernel writes sample words the previous batch's accumulate pass reads: it starts behind it)
             hipStream_t ss = fork ? ws->side : stream;
+            TimedLaunch* ts = nullptr;
             if (fork) {
                 HIP_TRY(hipEventRecord(ws->ev_fork, stream));
                 HIP_TRY(hipStreamWaitEvent(ss, ws->ev_fork, 0));
             }
             if (timed_kernels) {
-                rc = timed_slot(ws, &tl);
-                if (rc) return rc;
-                tl->kind = 2;
-                tl->launches = 1;
-                HIP_TRY(hipEventRecord(tl->a, ss));
+                const int trc = timed_slot(ws, &ts);
+                if (trc) return trc;
+                ts->kind = 2;
+                ts->launches = 1;
+                HIP_TRY(hipEventRecord(ts->a, ss));
             }
             rrt::launch_sky(s->dscene, wk, fr, (int32_t*)d_ids, (double*)d_t, ss);
-            if (timed_kernels) HIP_TRY(hipEventRecord(tl->b, ss));
+            if (timed_kernels) HIP_TRY(hipEventRecord(ts->b, ss));
             if (fork) HIP_TRY(hipEventRecord(ws->ev_join, ss));
+            return RRT_OK;
+        };
+        if (pl.want_lists && sky_after == 0) {
+            rc = sky();
+            if (rc) return rc;
         }
         if (timed_kernels) {
             rc = timed_slot(ws, &tl);
@@ -894,8 +911,12 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
             HIP_TRY(hipEventRecord(tl->a, stream));
         }
         rrt::launch_primary(s->dscene, s->d_dscene.as<rrt::DScene>(), wk, fr, (int32_t*)d_ids, (double*)d_t, stream);
+        if (timed_kernels) HIP_TRY(hipEventRecord(tl->b, stream));
+        if (pl.want_lists && sky_after == 1) {       // (takes a timing slot of its own: `tl` does not outlive this)
+            rc = sky();
+            if (rc) return rc;
+        }
         if (timed_kernels) {
-            HIP_TRY(hipEventRecord(tl->b, stream));
             // one event pair around the batch's bounce levels together (each hipEventRecord between two
             // launches costs ~3 us of idle GPU: ten events a frame were 1.5 % of it)
             rc = timed_slot(ws, &tl);
@@ -904,8 +925,15 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
             tl->launches = st->max_bounce + 1;
             HIP_TRY(hipEventRecord(tl->a, stream));
         }
-        for (uint32_t bounce = 1; bounce <= st->max_bounce + 1; ++bounce)
+        for (uint32_t bounce = 1; bounce <= st->max_bounce + 1; ++bounce) {
             rrt::launch_bounce(s->dscene, s->d_dscene.as<rrt::DScene>(), wk, fr, bounce, stream);
+            if (pl.want_lists && sky_after >= 2 && bounce == 1) {
+                const size_t slot = timed_kernels ? (size_t)(tl - ws->timed.data()) : 0;
+                rc = sky();
+                if (rc) return rc;
+                if (timed_kernels) tl = &ws->timed[slot];       // sky() may have grown the vector
+            }
+        }
         if (timed_kernels) HIP_TRY(hipEventRecord(tl->b, stream));
         if (fork) HIP_TRY(hipStreamWaitEvent(stream, ws->ev_join, 0));
         const bool last = b + 1 == pl.n_batches;
