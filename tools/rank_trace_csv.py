@@ -37,7 +37,7 @@ for k in order:
     print("one_frame_at_a_time,%s,%g,%.1f,%.1f,%.1f,%.1f" % (k, rn.get(k, 0), r, f, f / 8, r - f / 8))
     if k != "k_sky":
         tr += r; tf += f
-print("one_frame_at_a_time,sum_without_k_sky (k_sky runs beside the primary kernel),,%.1f,%.1f,%.1f,%.1f" % (tr, tf, tf / 8, tr - tf / 8))
+print("one_frame_at_a_time,sum_without_k_sky (k_sky runs beside the bounce levels),,%.1f,%.1f,%.1f,%.1f" % (tr, tf, tf / 8, tr - tf / 8))
 print("one_frame_at_a_time,frame_to_frame (with launch gaps),,%.1f,%.1f,%.1f,%.1f" % (rspan, fspan, fspan / 8, rspan - fspan / 8))
 for line in open("gpurun_out/%s_rt_inflight.log" % tag):
     m = re.match(r"world (\d+) spp (\d+) \S+ ms/frame with \[4\] frames in flight: ([\d.]+)", line)
