@@ -529,7 +529,7 @@ def main():
                     "heavy_tiles": heavy_t, "sky_tiles": sky_t,
                     "k_sky": {"ms_per_step": stats["sky_kernel_ms"], "rays_per_launch": sky_rays_per_launch,
                               "what": "the primary rays of the sky-only tiles (no entity can be met in the tile): texel lookups, "
-                                      "on a second stream beside k_wave_primary; not part of `achieved`"},
+                                      "on a second stream, forked off behind k_wave_primary (beside the bounce levels); not part of `achieved`"},
                     "other_kernels": {"k_wave_bounce_ms_per_step": bnc_ms, "k_wave_bounce_launches": bnc_n,
                                       "k_wave_primary_ms_per_step": prim_ms, "gpu_ms_per_step": stats["gpu_ms"]}}
             traffic = attach_profiles(roof, args.config)

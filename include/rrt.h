@@ -105,7 +105,7 @@ typedef struct rrt_stats {
     uint64_t level_rays[4];    /* rays cast at bounce level 0,1,2,3 (level 0 = primary)               */
     uint64_t cull_violations;  /* cull mode 2 only: entries the cull skipped but the exact test accepts (must be 0) */
     uint64_t zero_mix_paths;   /* primary hits whose reflection ray was cast with mix() == 0.0           */
-    double sky_kernel_ms;      /* summed hipEvent duration of the sky-only kernel launches (they run beside the primary kernel) */
+    double sky_kernel_ms;      /* summed hipEvent duration of the sky-only kernel launches (they run on a side stream, beside the bounce levels) */
     uint32_t heavy_tiles;      /* tiles of this rank whose primary rays went through the wavefront kernels ...         */
     uint32_t sky_tiles;        /* ... and tiles behind which there is only sky (0 / 0 for a frame without tile lists)  */
 } rrt_stats;
