@@ -319,6 +319,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Where the sky-only tiles' kernel runs (rrt_set_sky_stream): on a side stream behind the primary kernel, or on the
+    # frame's own stream.  One frame at a time the side stream always wins.  With frames in flight it depends on which
+    # of the process's streams share a hardware queue (the runtime deals every stream ever created to four of them):
+    # measured on one MI355X, the side stream is 4-18 % ahead in a process of its own and as much behind once an RCCL
+    # communicator exists.  So a pipelining caller tries both, untimed, before its warm-up -- every rank takes the same
+    # decision from the slowest rank's times.
+    sky_mode = [1]
+    sky_picks = []
+
+    def pick_sky_stream(step, in_flight, reps=3):
+        if in_flight <= 1 or os.environ.get("RRT_BENCH_SKY_STREAM", "") in ("0", "1"):
+            mode = int(os.environ.get("RRT_BENCH_SKY_STREAM", "1") or 1) if in_flight > 1 else 1
+            scene.set_sky_stream(mode)
+            return mode
+        best = {}
+        for mode in (1, 0):
+            scene.set_sky_stream(mode)
+            for _ in range(2 * in_flight):
+                step()
+            ts = []
+            for _ in range(reps):
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(3 * in_flight):
+                    step()
+                torch.cuda.synchronize()
+                ts.append(D.max_over_ranks(time.perf_counter() - t0, dev))
+            best[mode] = min(ts)
+        mode = 1 if best[1] <= best[0] * 1.01 else 0       # the default unless the other is clearly ahead
+        sky_picks.append({"in_flight": in_flight, "ms_side_stream": best[1] / (3 * in_flight) * 1e3, "ms_own_stream": best[0] / (3 * in_flight) * 1e3, "chosen": mode})
+        scene.set_sky_stream(mode)
+        return mode
+
     def measure(spp_total, in_flight):
         """-> (list of block seconds [max over ranks], stats of this rank's last frame)"""
         st = Hst.make_settings(w, h, spp=spp_total, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune,
@@ -334,6 +367,7 @@ def main():
             else:
                 pipe.step(st)
 
+        sky_mode[0] = pick_sky_stream(step, in_flight)
         for _ in range(max(args.warmup, in_flight)):
             step()
         blocks, total = [], 0.0
@@ -359,6 +393,7 @@ def main():
             [stats["rays_traced"], stats["paths"], stats["traversal_overflow"]], dev)
         med = median(blocks)
         return {"value": rays_step * args.steps / med / 1e6, "ms_per_step": med / args.steps * 1e3, "spp_total": spp_total,
+                "sky_stream": sky_mode[0],
                 "rays_per_step": rays_step, "samples_per_step": paths_step, "traversal_overflow": overflow,
                 "timing": {"blocks": len(blocks), "steps_per_block": args.steps,
                            "ms_per_step_min": min(blocks) / args.steps * 1e3, "ms_per_step_median": med / args.steps * 1e3,
@@ -436,6 +471,12 @@ def main():
         def frame_ms(tile_rank, tile_world, outs):
             st = Hst.make_settings(w, h, spp=STRONG_SPP, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune,
                                    tile_rank=tile_rank, tile_world=tile_world, tile_deal=deal if tile_world > 1 else 0)
+            count = [0]
+
+            def one():
+                scene.render_device(st, outs[count[0] % depth].data_ptr(), stream=streams[count[0] % depth].cuda_stream)
+                count[0] += 1
+            rank_modes.append(pick_sky_stream(one, depth, reps=2))
             n = 12
             ts = []
             for rep in range(4):
@@ -447,13 +488,16 @@ def main():
                 ts.append((time.perf_counter() - t0) / n * 1e3)
             return median(ts[1:])
         scene.set_timing(0)      # as the N-rank path runs it
+        rank_modes = []
         t_full = frame_ms(0, 1, frames)
         torch.cuda.synchronize()
         full_stats = scene.stats()
         full_rays = int(full_stats["rays_traced"])
         locals_ = [D.alloc_tile_buffers(w, h, 8, dev, dealt=bool(deal))[0] for _ in range(depth)]
         t_rank = [frame_ms(r, 8, locals_) for r in range(8)]
+        scene.set_sky_stream(1)
         rank_share = {"tile_world": 8, "tile_deal": deal, "spp_total": STRONG_SPP, "frames_in_flight": depth, "t_full_ms": t_full, "t_rank_ms": t_rank,
+                      "sky_stream": rank_modes,      # [whole frame, rank 0 .. 7]: what pick_sky_stream chose for each
                       "rank_share_efficiency": (t_full / 8.0) / max(t_rank),
                       # the same frame as `value` above, re-timed here next to the rank frames (host clock, 12 frames)
                       "strong_frame_one_gpu": {"spp_total": STRONG_SPP, "ms_per_step": t_full, "rays_per_step": full_rays,
@@ -491,6 +535,8 @@ def main():
                        "n_batches": stats["n_batches"], "level_rays": stats["level_rays"]},
         }
         line["config"]["frames_in_flight"] = depth
+        line["config"]["sky_stream"] = main_fig.get("sky_stream", 1)      # 1 = side stream, 0 = the frame's own (pick_sky_stream)
+        line["config"]["sky_stream_picks"] = sky_picks                    # every decision of this run, in order, with both timings
         if sequential is not None:
             line["one_frame_at_a_time"] = {"value": sequential["value"], "ms_per_step": sequential["ms_per_step"],
                                            "timing": sequential["timing"],

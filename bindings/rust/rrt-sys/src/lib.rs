@@ -107,6 +107,7 @@ extern "C" {
     pub fn rrt_set_work_budget(s: *mut rrt_scene, bytes: u64) -> c_int;
     pub fn rrt_set_cull_mode(s: *mut rrt_scene, mode: c_int) -> c_int;
     pub fn rrt_set_timing(s: *mut rrt_scene, level: c_int) -> c_int;
+    pub fn rrt_set_sky_stream(s: *mut rrt_scene, mode: c_int) -> c_int;
     /// Inspection of a primary-ray coverage mask: one byte per pixel (1 = some triangle of the mesh may accept a ray
     /// through it) and the "every pixel counts as set" flag.
     pub fn rrt_cover_mask(s: *mut rrt_scene, cam: *const rrt_camera, width: u32, height: u32, entity: c_int,

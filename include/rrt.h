@@ -258,6 +258,15 @@ int rrt_set_cull_mode(rrt_scene* s, int mode);
  * sub-millisecond frames back to back (one rank of a tile-sharded frame) turns them off. */
 int rrt_set_timing(rrt_scene* s, int level);
 
+/* Where the kernel of the sky-only tiles runs (no reference counterpart; scheduling only, the image is the same):
+ * 1 (default) = on a side stream of the frame's stream, forked off behind the primary kernel, so that it fills what
+ * the bounce levels leave idle -- what a caller that renders one frame at a time wants (1080p/64 spp: 3.56 ms
+ * against 3.9); 0 = on the frame's own stream, in front of the primary kernel.  With several frames in flight on
+ * several streams either can be the faster one by 4-18 %: the runtime deals streams to a few hardware queues, and
+ * which streams share one depends on every stream the process has created (an RCCL communicator made before the
+ * first frame turns the order round).  A caller that pipelines measures both once (bench.py, TilePipeline.autotune). */
+int rrt_set_sky_stream(rrt_scene* s, int mode);
+
 /* Uploads the scene to the device (idempotent; render calls it if needed). */
 int rrt_scene_commit(rrt_scene* s);
 

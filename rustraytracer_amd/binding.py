@@ -43,7 +43,7 @@ EXPORTS = [
     "rrt_default_camera", "rrt_default_settings", "rrt_scene_create", "rrt_scene_destroy",
     "rrt_add_material", "rrt_add_material_ext", "rrt_add_sphere", "rrt_add_mesh", "rrt_add_triangle", "rrt_add_group", "rrt_set_sky_face",
     "rrt_set_directional_light", "rrt_add_directional_light", "rrt_set_ambient", "rrt_add_point_light", "rrt_set_shadow_mode", "rrt_translate_entity",
-    "rrt_occluded_rays", "rrt_set_work_budget", "rrt_set_cull_mode", "rrt_set_timing",
+    "rrt_occluded_rays", "rrt_set_work_budget", "rrt_set_cull_mode", "rrt_set_timing", "rrt_set_sky_stream",
     "rrt_scene_commit",
     "rrt_render", "rrt_alloc_host_pinned", "rrt_free_host_pinned", "rrt_release_stream", "rrt_render_device", "rrt_render_device_noalloc", "rrt_noalloc_scratch_bytes", "rrt_tile_slots", "rrt_tile_buffer_bytes", "rrt_tile_skew", "rrt_comm_unique_id", "rrt_comm_init", "rrt_comm_destroy", "rrt_gather_tiles", "rrt_gather_tiles_dealt", "rrt_assemble_tiles", "rrt_assemble_tiles_dealt",
     "rrt_trace_rays", "rrt_cast_rays", "rrt_get_stats", "rrt_mesh_tree_sizes",
@@ -97,6 +97,7 @@ def _load():
     L.rrt_set_work_budget.argtypes = [vp, u64]
     L.rrt_set_cull_mode.argtypes = [vp, i32]
     L.rrt_set_timing.argtypes = [vp, i32]
+    L.rrt_set_sky_stream.argtypes = [vp, i32]
     L.rrt_scene_commit.argtypes = [vp]
     L.rrt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp]
     L.rrt_render_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Settings), vp, vp, vp, vp, vp]

@@ -156,6 +156,7 @@ struct rrt_scene {
     uint64_t work_budget = 48ull << 30;   // of 288 GB, per stream a scene renders on; a batch is also capped at 178.9 M paths (plan_frame)
     int cull_mode = 1;
     int timing = 2;        // rrt_set_timing: 0 no events, 1 frame begin/end, 2 + per-kernel pairs
+    int sky_stream = 1;    // rrt_set_sky_stream: 1 = the sky-only kernel on a side stream, 0 = on the frame's own
 
     bool dirty = true;
     DevBuf d_ents, d_spheres, d_meshes, d_mats, d_groups, d_lights, d_tri_ents, d_mesh_stage;
@@ -852,7 +853,7 @@ int render_device(rrt_scene* s, const rrt_camera* cam, const rrt_settings* st, v
     // The sky-only tiles run beside the wavefront kernels on a stream of their own (RRT_SKY_FORK=0, and the entry
     // point that allocates nothing: in front of them on the same stream).
     static const bool fork_on = [] { const char* e = getenv("RRT_SKY_FORK"); return !e || atoi(e) != 0; }();
-    const bool fork = pl.want_lists && !NOALLOC && fork_on;
+    const bool fork = pl.want_lists && !NOALLOC && fork_on && s->sky_stream != 0;
     if (fork && !ws->side) {
         HIP_TRY(hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming));
@@ -1305,6 +1306,12 @@ int rrt_set_ambient(rrt_scene* s, double ambient) {
 int rrt_set_work_budget(rrt_scene* s, uint64_t bytes) {
     if (!s) return fail(RRT_E_INVALID, "null scene");
     s->work_budget = bytes;
+    return RRT_OK;
+}
+
+int rrt_set_sky_stream(rrt_scene* s, int mode) {
+    if (!s || mode < 0 || mode > 1) return fail(RRT_E_INVALID, "sky stream mode must be 0 or 1");
+    s->sky_stream = mode;
     return RRT_OK;
 }
 

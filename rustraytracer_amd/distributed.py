@@ -124,6 +124,34 @@ class TilePipeline:
             self.ev_comm[k].record(self.s_comm)
         self.i += 1
 
+    def autotune(self, settings, reps=3):
+        """Picks where the sky-only tiles' kernel runs (World.set_sky_stream) for this pipeline: both placements are
+        timed over 3 * depth frames, `reps` times, and the faster one stays (the side stream unless the frame's own is
+        more than 1 % ahead).  With frames in flight the better one depends on which of the process's streams share a
+        hardware queue -- an RCCL communicator created before the first frame is enough to turn it round -- so it is
+        measured, once, before the frames that count.  Every rank takes the same decision (slowest rank's times).
+        Returns the mode chosen."""
+        import time
+        best = {}
+        for mode in (1, 0):
+            self.scene.set_sky_stream(mode)
+            for _ in range(2 * self.depth):
+                self.step(settings)
+            ts = []
+            for _ in range(reps):
+                if dist.is_initialized() and dist.get_world_size() > 1:
+                    dist.barrier()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3 * self.depth):
+                    self.step(settings)
+                torch.cuda.synchronize()
+                ts.append(max_over_ranks(time.perf_counter() - t0, self.frame.device))
+            best[mode] = min(ts)
+        mode = 1 if best[1] <= best[0] * 1.01 else 0
+        self.scene.set_sky_stream(mode)
+        return mode
+
 
 def max_over_ranks(seconds, device):
     multi = dist.is_initialized() and dist.get_world_size() > 1

@@ -165,6 +165,10 @@ class World:
     def set_timing(self, level):
         B.check(B.lib.rrt_set_timing(self.h, int(level)))
 
+    def set_sky_stream(self, mode):
+        """1 (default): the sky-only tiles' kernel on a side stream behind the primary kernel; 0: on the frame's own stream."""
+        B.check(B.lib.rrt_set_sky_stream(self.h, int(mode)))
+
     def commit(self):
         B.check(B.lib.rrt_scene_commit(self.h))
 

@@ -49,3 +49,32 @@ def test_every_placement_of_the_sky_kernel_gives_the_same_frame():
     assert len(want) == len(hashlib.sha256().hexdigest())
     for extra in ({"RRT_SKY_AFTER": "0"}, {"RRT_SKY_AFTER": "2"}, {"RRT_SKY_FORK": "0"}):
         assert _digest(extra) == want, extra
+
+
+def test_sky_stream_setter_changes_nothing_but_the_schedule():
+    """rrt_set_sky_stream (what a pipelining caller switches at run time, TilePipeline.autotune): the same frames with
+    the sky-only kernel on the side stream and on the frame's own stream, alternating on one scene and with frames of
+    both kinds in flight on two streams."""
+    import numpy as np
+    import torch
+    from rustraytracer_amd import host as H, scenes
+    g = scenes.main_rs_scene(H.World(device=0), H.loaders)
+    want = g.render(1920, 1080, spp=2, seed=11, want=("rgb", "ids", "t"))
+    for mode in (0, 1, 0):
+        g.set_sky_stream(mode)
+        got = g.render(1920, 1080, spp=2, seed=11, want=("rgb", "ids", "t"))
+        for k in ("rgb", "ids", "t"):
+            assert np.array_equal(got[k], want[k]), (mode, k)
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = [torch.zeros((1080, 1920, 3), dtype=torch.uint8, device="cuda:0") for _ in range(4)]
+    st = H.make_settings(1920, 1080, spp=2, seed=11)
+    torch.cuda.synchronize()
+    for i in range(4):
+        g.set_sky_stream(i & 1)
+        g.render_device(st, outs[i].data_ptr(), stream=streams[i % 2].cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(4):
+        assert np.array_equal(outs[i].cpu().numpy(), want["rgb"]), i
+    with pytest.raises(Exception, match="sky stream"):
+        g.set_sky_stream(2)
+    g.set_sky_stream(1)

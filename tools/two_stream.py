@@ -12,11 +12,19 @@ world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 dev = torch.device("cuda", 0)
+if os.environ.get("NCCL1"):      # an RCCL communicator (world of one) before anything renders: its streams exist first, as in bench.py --gpus N
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    t = torch.ones(1024, device=dev); dist.all_reduce(t); torch.cuda.synchronize()
 cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
 bufs, streams = [], []
 w = getattr(scenes, cfg + "_scene")(H.World(device=0), H.loaders)
 w.commit()
 w.set_timing(0)
+if os.environ.get("SKY_STREAM"):
+    w.set_sky_stream(int(os.environ["SKY_STREAM"]))
 NS = [int(x) for x in os.environ.get('NSTREAMS', '1,2,3,4').split(',')]
 for i in range(max(NS)):
     if world > 1:
