@@ -20,6 +20,13 @@ if os.environ.get("NCCL1"):      # an RCCL communicator (world of one) before an
     t = torch.ones(1024, device=dev); dist.all_reduce(t); torch.cuda.synchronize()
 cfg = sys.argv[4] if len(sys.argv) > 4 else "cfg2"
 bufs, streams = [], []
+_extra = []
+for _p in [int(x) for x in os.environ.get("EXTRA_STREAMS", "").split(",") if x]:      # extra streams of these priorities, each used once, before anything renders
+    _s = torch.cuda.Stream(device=dev, priority=_p)
+    with torch.cuda.stream(_s):
+        torch.ones(16, device=dev).add_(1)
+    _extra.append(_s)
+torch.cuda.synchronize()
 w = getattr(scenes, cfg + "_scene")(H.World(device=0), H.loaders)
 w.commit()
 w.set_timing(0)
@@ -32,6 +39,8 @@ for i in range(max(NS)):
     else:
         bufs.append(torch.empty(1080 * 1920 * 3, dtype=torch.uint8, device=dev))
     streams.append(torch.cuda.Stream(device=dev))
+    for _ in range(int(os.environ.get("SPACING", "1")) - 1):      # skip streams of torch's pool: which hardware queues the frames' streams share
+        torch.cuda.Stream(device=dev)
 deal = int(os.environ.get("DEAL", "1")) if world > 1 else 0
 st = H.make_settings(1920, 1080, spp=spp, tile_rank=int(os.environ.get("RANK_", "2")) % world, tile_world=world, tile_deal=deal)
 
