@@ -477,9 +477,9 @@ def main():
                 scene.render_device(st, outs[count[0] % depth].data_ptr(), stream=streams[count[0] % depth].cuda_stream)
                 count[0] += 1
             rank_modes.append(pick_sky_stream(one, depth, reps=2))
-            n = 12
+            n = 16
             ts = []
-            for rep in range(4):
+            for rep in range(8):      # the first is dropped, the median of seven stays (max over eight ranks of a noisy figure reads high)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for i in range(n):
@@ -499,11 +499,11 @@ def main():
         rank_share = {"tile_world": 8, "tile_deal": deal, "spp_total": STRONG_SPP, "frames_in_flight": depth, "t_full_ms": t_full, "t_rank_ms": t_rank,
                       "sky_stream": rank_modes,      # [whole frame, rank 0 .. 7]: what pick_sky_stream chose for each
                       "rank_share_efficiency": (t_full / 8.0) / max(t_rank),
-                      # the same frame as `value` above, re-timed here next to the rank frames (host clock, 12 frames)
+                      # the same frame as `value` above, re-timed here next to the rank frames (host clock, 16 frames)
                       "strong_frame_one_gpu": {"spp_total": STRONG_SPP, "ms_per_step": t_full, "rays_per_step": full_rays,
                                                "value": full_rays / t_full / 1e3, "unit": "Mrays/s"},
                       "what": "T(full)/8 over max_r T(rank r of 8), each measured alone on this one GPU with the bench's frames in "
-                              "flight, host-timed with a device sync around 12 frames; excludes the RCCL gather (0.78 MB per rank)"}
+                              "flight, host-timed with a device sync around 16 frames (median of 7 such blocks); excludes the RCCL gather (0.78 MB per rank)"}
         # leave the work buffers sized for the bench frame again
         scene.set_timing(2)
         st = Hst.make_settings(w, h, spp=spp0, max_bounce=max_bounce, seed=0, prune_zero_mix=args.prune, batch_spp=args.batch_spp)
