@@ -100,3 +100,36 @@ def test_noalloc_sharded_frame_and_limits(H, scenes):
     g.set_ambient(0.2)
     st = H.make_settings(64, 64)
     assert B.lib.rrt_render_device_noalloc(g.h, C.byref(cam), C.byref(st), out.data_ptr(), None, None, None, None) == -3
+
+
+def test_noalloc_frame_under_graph_capture(H, scenes):
+    """What the entry point is for: its launch chain captured into a HIP graph (nothing in it allocates, creates an
+    event or synchronises) and replayed -- the replays leave the bytes rrt_render_device leaves, also after the output
+    buffer was cleared in between and after a direct call with other settings has used the scratch array."""
+    import torch
+    g = scenes.main_rs_scene(H.World(device=0), H.loaders)
+    g.commit()
+    w, h = 640, 360
+    st = H.make_settings(w, h, spp=2, seed=21)
+    ref = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda:0")
+    g.render_device(st, ref.data_ptr())
+    torch.cuda.synchronize()
+    out = torch.zeros_like(ref)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g.render_device_noalloc(st, out.data_ptr(), stream=s.cuda_stream)      # outside capture once: set-up paths
+    s.synchronize()
+    assert torch.equal(out, ref)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        g.render_device_noalloc(st, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        out.zero_()
+        if rep == 2:      # other contents in the scratch array before the replay
+            other = torch.zeros((200, 300, 3), dtype=torch.uint8, device="cuda:0")
+            g.render_device_noalloc(H.make_settings(300, 200, spp=1, seed=4), other.data_ptr())
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), rep
