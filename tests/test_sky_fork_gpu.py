@@ -78,3 +78,33 @@ def test_sky_stream_setter_changes_nothing_but_the_schedule():
     with pytest.raises(Exception, match="sky stream"):
         g.set_sky_stream(2)
     g.set_sky_stream(1)
+
+
+def test_tile_pipeline_autotune_keeps_one_placement_and_the_frame():
+    """TilePipeline.autotune times both placements over the pipeline's own frames in flight and leaves the scene on one
+    of them.  One process stands for rank 1 of 2 (no process group: the gather copies this rank's tiles into slot 0 of
+    the gathered buffer, the other rank's stay zero), so what the pipeline assembles must be the frame's tiles of rank 1
+    where the de-interleave puts rank 0's -- after the tuning and for the next frame."""
+    import numpy as np
+    import torch
+    from rustraytracer_amd import host as H, scenes, distributed as D, tiles
+    g = scenes.main_rs_scene(H.World(device=0), H.loaders)
+    W, Hh, world, rank = 1920, 1080, 2, 1
+    full = g.render(W, Hh, spp=1, seed=2, want=("rgb",))["rgb"]
+    gathered = np.zeros((world,) + tiles.extract_rank_tiles(full, rank, world).shape, np.uint8)
+    gathered[0] = tiles.extract_rank_tiles(full, rank, world)
+    want = tiles.assemble_numpy(gathered, W, Hh, world)
+    assert want.any()
+    dev = torch.device("cuda", 0)
+    frame = torch.zeros((Hh, W, 3), dtype=torch.uint8, device=dev)
+    pipe = D.TilePipeline(g, W, Hh, world, dev, frame, depth=3)
+    st = H.make_settings(W, Hh, spp=1, seed=2, tile_rank=rank, tile_world=world)
+    mode = pipe.autotune(st, reps=1)
+    assert mode in (0, 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), want)
+    frame.zero_()
+    pipe.step(st)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), want)
+    g.set_sky_stream(1)
